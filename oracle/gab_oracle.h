@@ -1,0 +1,155 @@
+/*
+ * gab_oracle.h — CPU oracle for the gpuaudiobench hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it, and only as the
+ * checker.  Nothing under gpuaudiobench_amd/ links, imports or calls it.
+ *
+ * It is a plain-C restatement of the reference's in-binary CPU golden
+ * functions (tskare/gpuaudiobench, cuda/ tree); every function cites the
+ * reference file:line it follows.
+ *
+ * Pinning.  The reference cuda/ tree cannot be built in this image: every
+ * translation unit includes <cuda_runtime.h>, <helper_cuda.h>, <cufft.h>
+ * (cuda/bench_utils.cuh:3-4, cuda/bench_utils.cu:2) which the image lacks,
+ * and writing stand-ins for them is not allowed, so there is no oracle/_ref.
+ * The reference also ships no tests or fixtures.  This restatement is pinned
+ * against the known-answer values recorded in SURVEY.md §8c (first values,
+ * sums and FNV-1a-64 hashes of every golden, captured at survey time from the
+ * reference's own golden functions) — see tests/test_oracle_pins.py.
+ * Not pinned by any reference output ("parity unpinned" there): the real
+ * FDTD3D field evolution (the reference golden is a placeholder), streaming
+ * conv1d_accel beyond the first buffer, the real modal bank.
+ *
+ * Build: gcc -O2 -ffp-contract=off (see oracle/Makefile).  Contraction is off
+ * so a*b+c is two roundings, as in the reference's host build; where the
+ * CUDA *kernel* is the spec (FDTD3D) the fused form is an explicit fmaf().
+ */
+#ifndef GAB_ORACLE_H
+#define GAB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- hashing / helpers ------------------------------------------------- */
+uint64_t orc_fnv1a64(const void* data, size_t nbytes);
+/* variant (offset basis 1469598103934665603) the SURVEY §8c pins were taken with */
+uint64_t orc_fnv1a64_survey(const void* data, size_t nbytes);
+
+/* ---- random sources ---------------------------------------------------- */
+/* std::mt19937(seed) + std::uniform_real_distribution<float>(-1,1) as
+ * libstdc++ evaluates it (cuda/bench_utils.cu:238-245). */
+void orc_noise_mt19937(float* buf, size_t n, uint32_t seed);
+
+/* glibc rand()/srand() (TYPE_3 additive feedback generator), reentrant.
+ * seed 1 == the state of a process that never called srand(). */
+typedef struct { uint32_t r[34]; int f, b; } orc_rand_t;
+void orc_srand(orc_rand_t* st, unsigned seed);
+int  orc_rand(orc_rand_t* st);                      /* 0 .. 2147483647 */
+#define ORC_RAND_MAX 2147483647
+/* n draws of (float)rand()/(float)RAND_MAX                                 */
+void orc_rand_unit(orc_rand_t* st, float* buf, size_t n);
+/* n draws of ((float)rand()/(float)RAND_MAX)*2.0f-1.0f                     */
+void orc_rand_bipolar(orc_rand_t* st, float* buf, size_t n);
+
+/* ---- gain / gainstats / noop / datatransfer ---------------------------- */
+void orc_gain(const float* in, float* out, size_t n, float gain);
+void orc_gainstats(const float* in, float* out, float* stats,
+                   size_t tracks, size_t bufsize);
+void orc_noop(const float* in, float* out, size_t n);
+int  orc_datatransfer_size(float ratio);            /* int(2621440*ratio) */
+void orc_datatransfer(const float* in, float* out, int in_size, int out_size);
+
+/* ---- FFT --------------------------------------------------------------- */
+/* input generator of FFTBenchmark::setupBenchmark (rand stream continues in st) */
+void orc_fft_input(orc_rand_t* st, float* in, size_t tracks, size_t bufsize);
+/* naive fp32 DFT, 513 bins per 1024-sample track (the reference golden)    */
+void orc_fft_golden(const float* in, float* re, float* im, size_t tracks);
+/* float64 DFT of the same input (truth for the parity gate) */
+void orc_fft_truth(const float* in, double* re, double* im, size_t tracks);
+
+/* ---- IIR --------------------------------------------------------------- */
+typedef struct { float b0, b1, b2, a1, a2; } orc_iir_coeffs;
+orc_iir_coeffs orc_iir_butterworth(float normalized_frequency);
+void orc_iir(const float* in, float* out, const orc_iir_coeffs* c,
+             float* state, int tracks, int bufsize);
+
+/* ---- time-domain conv1d ------------------------------------------------ */
+void orc_conv1d_ir(float* ir, int ir_len, size_t tracks);
+void orc_conv1d(const float* in, const float* ir, float* out,
+                int ir_len, int bufsize, int tracks);
+
+/* ---- conv1d_accel ------------------------------------------------------ */
+/* IR bank; track_offset/total_tracks let a shard generate its slice of the
+ * global bank (the formula uses the GLOBAL track index and count).         */
+void orc_conv_accel_ir(float* ir, int ir_len, size_t track_offset,
+                       size_t n_tracks, size_t total_tracks);
+/* reference golden: zero history, sample-major output                      */
+void orc_conv_accel(const float* in, const float* ir, float* out,
+                    int ir_len, int bufsize, int tracks);
+/* streaming extension (not pinned by the reference): `hist` holds the last
+ * ir_len samples per track (track-major [t*ir_len + i], oldest first) and is
+ * updated in place; fp32 accumulation in the golden's k-ascending order.   */
+void orc_conv_accel_stream(const float* in, const float* ir, float* out,
+                           float* hist, int ir_len, int bufsize, int tracks);
+/* same, accumulating in float64 (truth for error budgets)                  */
+void orc_conv_accel_stream_f64(const float* in, const float* ir, double* out,
+                               float* hist, int ir_len, int bufsize, int tracks);
+
+/* ---- modal (placeholder semantics of the CUDA port) -------------------- */
+void orc_modal_params(float* params, int n_modes);            /* srand(42) */
+void orc_modal(const float* params, float* out, int n_modes, int bufsize,
+               int out_tracks);
+
+/* ---- digital waveguide -------------------------------------------------- */
+typedef struct {
+    int length, inputTapPos, outputTapPos, writePos;
+    float gain, reflection, damping, padding;
+} orc_wg_state;                                               /* 32 bytes  */
+/* waveguide states (srand(42)) then the input signal drawn from the SAME
+ * stream (cuda/bench_dwg.cu:166-180, 325-348)                              */
+void orc_dwg_init(orc_wg_state* wg, float* input, int n_wg, int bufsize);
+void orc_dwg(const orc_wg_state* wg, float* fwd, float* bwd,
+             const float* input, float* out, int n_wg, int bufsize,
+             int max_len, int out_tracks);
+
+/* ---- FDTD3D ------------------------------------------------------------- */
+typedef struct {
+    int nx, ny, nz;
+    int src_x, src_y, src_z, rcv_x, rcv_y, rcv_z;
+    int steps_per_sample;
+    float dt_over_rho_dx, rho_c2_dt_over_dx, absorption;
+} orc_fdtd_params;
+/* reference defaults for an nx*ny*nz grid (52^3 in the reference)          */
+orc_fdtd_params orc_fdtd_default_params(int nx, int ny, int nz);
+/* the in-file placeholder golden (cuda/bench_fdtd3d.cu:445-459)            */
+void orc_fdtd_placeholder(const float* in, float* out, int tracks, int bufsize);
+/* real field evolution restating the four CUDA kernels; grids are caller-
+ * owned and carried across calls. fused!=0 uses fmaf where nvcc contracts. */
+void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
+              float* vz, const float* in, float* out, int tracks, int bufsize,
+              int first_sample, int n_samples, int fused);
+
+/* ---- rndmem -------------------------------------------------------------- */
+void orc_rndmem_pool(float* pool, size_t n);                  /* srand(42) */
+void orc_rndmem_playheads(int* playheads, float* starts, float* ends,
+                          int tracks, int bufsize, size_t pool_elems,
+                          int min_loop, int max_loop);
+void orc_rndmem_advance(int* playheads, const float* starts, const float* ends,
+                        int tracks, int bufsize);
+void orc_rndmem(const float* pool, const int* playheads, float* out,
+                int bufsize, int tracks);
+
+/* ---- harness statistics (cuda/bench_utils.cu:358-414) -------------------- */
+typedef struct { float mean, median, std_dev, min_val, max_val, p95, p99;
+                 size_t count; } orc_stats;
+orc_stats orc_statistics(const float* lat, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
