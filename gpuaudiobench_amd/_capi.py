@@ -1,0 +1,116 @@
+"""ctypes binding of libgab_hip.so (include/gab_c_api.h).
+
+There is no CPU fallback: if the shared object is missing or a symbol is
+absent, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgab_hip.so")
+
+GAB_OK = 0
+GAB_ERR_INVALID_ARG = -1
+GAB_ERR_RUNTIME = -2
+GAB_ERR_UNSUPPORTED = -3
+
+CONV_STATELESS = 0
+CONV_STREAMING = 1
+DWG_NAIVE = 0
+DWG_ACCEL = 1
+
+
+class GabError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("gab error %d: %s" % (code, text))
+        self.code = code
+
+
+class WaveguideState(C.Structure):
+    _fields_ = [("length", C.c_int), ("inputTapPos", C.c_int), ("outputTapPos", C.c_int),
+                ("writePos", C.c_int), ("gain", C.c_float), ("reflection", C.c_float),
+                ("damping", C.c_float), ("padding", C.c_float)]
+
+
+class FdtdParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "nx", "ny", "nz", "source_x", "source_y", "source_z",
+        "receiver_x", "receiver_y", "receiver_z", "steps_per_sample")] + [
+            (n, C.c_float) for n in ("dt_over_rho_dx", "rho_c2_dt_over_dx", "absorption_coeff")]
+
+
+class BenchConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet")]
+
+
+class BenchResult(C.Structure):
+    _fields_ = [("iterations", C.c_int)] + [(n, C.c_float) for n in (
+        "mean_ms", "median_ms", "std_dev_ms", "min_ms", "max_ms", "p95_ms", "p99_ms",
+        "gpu_median_ms")] + [("throughput_gbps", C.c_double), ("samples_per_sec", C.c_double),
+                             ("bytes_processed", C.c_size_t)]
+
+
+class BenchValidation(C.Structure):
+    _fields_ = [("status", C.c_int), ("max_error", C.c_float), ("mean_error", C.c_float)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+
+# name -> (restype, argtypes).  Every prototype of include/gab_c_api.h is here;
+# tests/test_capi_symbols.py checks the two lists against each other.
+PROTOTYPES = {
+    "gab_version": (_I, []),
+    "gab_last_error": (C.c_char_p, []),
+    "gab_device_count": (_I, [C.POINTER(_I)]),
+    "gab_noop": (_I, [_P, _P, _Z, _P]),
+    "gab_gain": (_I, [_P, _P, _Z, _F, _P]),
+    "gab_gainstats": (_I, [_P, _P, _P, _I, _I, _F, _P]),
+    "gab_datatransfer": (_I, [_P, _P, _I, _I, _P]),
+    "gab_iir": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
+    "gab_conv1d": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "gab_rndmem": (_I, [_P, _P, _P, _I, _I, _P]),
+    "gab_modal": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gab_dwg_workspace_bytes": (_Z, [_I, _I]),
+    "gab_dwg": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "gab_fft_r2c_1024": (_I, [_P, _P, _I, _P]),
+    "gab_conv_create": (_I, [C.POINTER(_P), _I, _I, _I]),
+    "gab_conv_destroy": (_I, [_P]),
+    "gab_conv_set_ir": (_I, [_P, _P, _P]),
+    "gab_conv_reset": (_I, [_P, _P]),
+    "gab_conv_process": (_I, [_P, _P, _P, _I, _P]),
+    "gab_conv_state_bytes": (_I, [_P, C.POINTER(_Z), C.POINTER(_Z)]),
+    "gab_fdtd_default_params": (_I, [_I, _I, _I, C.POINTER(FdtdParams)]),
+    "gab_fdtd_create": (_I, [C.POINTER(_P), C.POINTER(FdtdParams)]),
+    "gab_fdtd_destroy": (_I, [_P]),
+    "gab_fdtd_reset": (_I, [_P, _P]),
+    "gab_fdtd_process": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "gab_fdtd_copy_pressure": (_I, [_P, _P, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gpuaudiobench_amd: %s is missing — build it with `python gpuaudiobench_amd/build.py` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    # torch first: it brings its own libamdhip64.so.7; loading ours afterwards
+    # binds to that same runtime instead of a second copy from /opt/rocm.
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != GAB_OK:
+        raise GabError(rc, lib.gab_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,227 @@
+// gab_fft.hpp — workgroup-level complex FFT for gfx950, registers + LDS.
+//
+// Replaces the cuFFT calls of the reference (cuda/bench_fft.cu:63,105;
+// cuda/bench_conv1d_accel.cu:137,144,211,276,289) with a Stockham autosort
+// transform that lives inside the calling kernel, so padding, spectral
+// multiply, normalisation and extraction fuse with it instead of costing a
+// pass over HBM each.
+//
+// Shape: N = R * NT complex points, NT threads, every thread owns exactly one
+// radix-R butterfly per pass (R values in registers).  Thread `tid` enters with
+// v[r] = x[tid + r*NT] and leaves with v[r] = X[tid + r*NT] — the same layout,
+// so a forward transform, a bin-wise product and an inverse transform chain
+// without any re-shuffle.  Between passes the values cross LDS once
+// (ds_write_b64 / ds_read_b64); indices are padded so the strided pass-0
+// stores stay bank-conflict free (32 write banks, 16-lane groups).
+//
+// Numerics: twiddles come from a table computed in float64 and rounded once;
+// complex products are 2 mul + 2 fma.  Contraction is otherwise off for the
+// whole library (-ffp-contract=off), so results do not depend on the optimiser.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace gab {
+namespace fft {
+
+struct cf { float x, y; };
+
+__device__ __forceinline__ cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf conj(cf a) { return mk(a.x, -a.y); }
+// (a.x + i a.y)(b.x + i b.y)
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    return mk(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+// a * conj(b)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+    return mk(__builtin_fmaf(a.x, b.x, a.y * b.y), __builtin_fmaf(a.y, b.x, -(a.x * b.y)));
+}
+// acc + a*b
+__device__ __forceinline__ cf cfma(cf a, cf b, cf acc) {
+    float re = __builtin_fmaf(a.x, b.x, acc.x);
+    re = __builtin_fmaf(-a.y, b.y, re);
+    float im = __builtin_fmaf(a.x, b.y, acc.y);
+    im = __builtin_fmaf(a.y, b.x, im);
+    return mk(re, im);
+}
+
+// multiply by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ cf rot90(cf a) {
+    return INV ? mk(-a.y, a.x) : mk(a.y, -a.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ void bfly2(cf& a, cf& b) {
+    cf t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+
+// 4-point DFT, natural order in and out.
+template <bool INV>
+__device__ __forceinline__ void bfly4(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    cf t2 = cadd(a1, a3), t3 = rot90<INV>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+// multiply by W16^m (forward: exp(-2*pi*i*m/16); inverse: conjugate)
+template <bool INV, int M>
+__device__ __forceinline__ cf tw16(cf a) {
+    constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
+    constexpr float H = 0.70710678118654752f;    // sqrt(1/2)
+    if constexpr (M == 0) return a;
+    else if constexpr (M == 4) return rot90<INV>(a);
+    else if constexpr (M == 2) {
+        // (x+iy)(H -/+ iH)
+        return INV ? mk((a.x - a.y) * H, (a.x + a.y) * H) : mk((a.x + a.y) * H, (a.y - a.x) * H);
+    } else if constexpr (M == 6) {
+        // (x+iy)(-H -/+ iH)
+        return INV ? mk(-(a.x + a.y) * H, (a.x - a.y) * H) : mk((a.y - a.x) * H, -(a.x + a.y) * H);
+    } else {
+        constexpr float wr = (M == 1) ? C1 : (M == 3) ? S1 : /* M == 9 */ -C1;
+        constexpr float wi = (M == 1) ? -S1 : (M == 3) ? -C1 : /* M == 9 */ S1;
+        return INV ? cmulc(a, mk(wr, wi)) : cmul(a, mk(wr, wi));
+    }
+}
+
+// In-register radix-R DFT.  Output k of the transform is left in v[out_slot(k)].
+template <int R, bool INV>
+struct Butterfly;
+
+template <bool INV>
+struct Butterfly<2, INV> {
+    __device__ static __forceinline__ void run(cf (&v)[2]) { bfly2<INV>(v[0], v[1]); }
+    __host__ __device__ static constexpr int out_slot(int k) { return k; }
+};
+
+template <bool INV>
+struct Butterfly<4, INV> {
+    __device__ static __forceinline__ void run(cf (&v)[4]) { bfly4<INV>(v[0], v[1], v[2], v[3]); }
+    __host__ __device__ static constexpr int out_slot(int k) { return k; }
+};
+
+template <bool INV>
+struct Butterfly<8, INV> {
+    // n = 2*n1 + n2 (n1 < 4, n2 < 2); k = k1 + 4*k2
+    __device__ static __forceinline__ void run(cf (&v)[8]) {
+        bfly4<INV>(v[0], v[2], v[4], v[6]);
+        bfly4<INV>(v[1], v[3], v[5], v[7]);
+        // y[k1][n2] sits in v[2*k1 + n2]; twiddle W8^(n2*k1) = W16^(2*n2*k1)
+        v[3] = tw16<INV, 2>(v[3]);
+        v[5] = tw16<INV, 4>(v[5]);
+        v[7] = tw16<INV, 6>(v[7]);
+        bfly2<INV>(v[0], v[1]);
+        bfly2<INV>(v[2], v[3]);
+        bfly2<INV>(v[4], v[5]);
+        bfly2<INV>(v[6], v[7]);
+    }
+    // X[k1 + 4*k2] is in v[2*k1 + k2]
+    __host__ __device__ static constexpr int out_slot(int k) { return 2 * (k & 3) + (k >> 2); }
+};
+
+template <bool INV>
+struct Butterfly<16, INV> {
+    // n = 4*n1 + n2; k = k1 + 4*k2
+    __device__ static __forceinline__ void run(cf (&v)[16]) {
+        bfly4<INV>(v[0], v[4], v[8], v[12]);
+        bfly4<INV>(v[1], v[5], v[9], v[13]);
+        bfly4<INV>(v[2], v[6], v[10], v[14]);
+        bfly4<INV>(v[3], v[7], v[11], v[15]);
+        // y[k1][n2] sits in v[4*k1 + n2]; twiddle W16^(n2*k1)
+        v[5] = tw16<INV, 1>(v[5]);
+        v[6] = tw16<INV, 2>(v[6]);
+        v[7] = tw16<INV, 3>(v[7]);
+        v[9] = tw16<INV, 2>(v[9]);
+        v[10] = tw16<INV, 4>(v[10]);
+        v[11] = tw16<INV, 6>(v[11]);
+        v[13] = tw16<INV, 3>(v[13]);
+        v[14] = tw16<INV, 6>(v[14]);
+        v[15] = tw16<INV, 9>(v[15]);
+        bfly4<INV>(v[0], v[1], v[2], v[3]);
+        bfly4<INV>(v[4], v[5], v[6], v[7]);
+        bfly4<INV>(v[8], v[9], v[10], v[11]);
+        bfly4<INV>(v[12], v[13], v[14], v[15]);
+    }
+    // X[k1 + 4*k2] is in v[4*k1 + k2]
+    __host__ __device__ static constexpr int out_slot(int k) { return 4 * (k & 3) + (k >> 2); }
+};
+
+constexpr int kTwiddleN = 4096;   // table holds exp(-2*pi*i*m/4096), m < 4096
+
+__host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+__host__ __device__ constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+__host__ __device__ constexpr int passes_of(int n, int r) { return n <= 1 ? 0 : 1 + passes_of(n / r, r); }
+
+// LDS image: logical index i lives at i + (i >> PADSH); one pad slot per
+// 2^PADSH entries breaks the power-of-two stride of the pass-0 stores.
+template <int R>
+struct Pad {
+    static constexpr int SH = ilog2(R);
+    __host__ __device__ static constexpr int at(int i) { return i + (i >> SH); }
+    __host__ __device__ static constexpr int size(int n) { return n + (n >> SH); }
+};
+
+// One workgroup-wide transform.  `ldsA`/`ldsB` each hold Pad<R>::size(N) cf.
+// All NT threads must call it (it contains barriers).  On return the two
+// buffers may be reused after the caller's next barrier.
+template <int N, int R, bool INV>
+struct BlockFFT {
+    static constexpr int NT = N / R;
+    static constexpr int PASSES = passes_of(N, R);
+    static_assert(ipow(R, PASSES) == N, "N must be a power of R");
+    static_assert(kTwiddleN % N == 0, "twiddle table too small");
+    using P = Pad<R>;
+
+    __device__ static __forceinline__ void run(cf (&v)[R], cf* __restrict__ ldsA,
+                                               cf* __restrict__ ldsB,
+                                               const cf* __restrict__ tw, int tid) {
+        cf* buf = ldsA;
+        cf* other = ldsB;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int Ns = ipow(R, p);
+            if (p > 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = buf[P::at(tid + r * NT)];
+                // twiddle W_{Ns*R}^(r*k), k = tid mod Ns
+                const int k = tid & (Ns - 1);
+                const int step = kTwiddleN / (Ns * R);
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+                    cf w = tw[(r * k * step) & (kTwiddleN - 1)];
+                    v[r] = INV ? cmulc(v[r], w) : cmul(v[r], w);
+                }
+                cf* t = buf; buf = other; other = t;
+            }
+            Butterfly<R, INV>::run(v);
+            if (p < PASSES - 1) {
+                const int base = (tid / Ns) * Ns * R + (tid & (Ns - 1));
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    buf[P::at(base + r * Ns)] = v[Butterfly<R, INV>::out_slot(r)];
+                __syncthreads();
+            } else {
+                // leave X[tid + r*NT] in v[r]
+                cf o[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) o[r] = v[Butterfly<R, INV>::out_slot(r)];
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = o[r];
+            }
+        }
+    }
+};
+
+// Host: fill the float64-accurate twiddle table (kTwiddleN complex floats).
+void build_twiddles(float* table_xy);
+
+}  // namespace fft
+}  // namespace gab

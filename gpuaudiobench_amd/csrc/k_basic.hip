@@ -1,0 +1,229 @@
+// k_basic.hip — bandwidth kernels: noop, gain, gainstats, datatransfer, modal,
+// rndmem.  Reference kernels are one-thread-per-track serial loops with a
+// stride-B (uncoalesced) access pattern (cuda/bench_gain.cu:6-24 etc.); here
+// every kernel is element- or wave-parallel with 16-byte coalesced accesses.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gab_common.hpp"
+
+namespace gab {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 2048;     // 256 CUs x 8 blocks: grid-stride beyond that
+
+inline int grid_for(size_t work_items) {
+    size_t g = (work_items + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)kMaxGrid ? kMaxGrid : g);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- noop / gain ------------------------------------------------------------
+// out = in * gain when SCALE, else a plain copy.  n4 float4 groups + scalar tail.
+template <bool SCALE>
+__global__ __launch_bounds__(kBlock) void scale_vec4_kernel(const float4* __restrict__ in,
+                                                           float4* __restrict__ out, size_t n4,
+                                                           const float* __restrict__ in_tail,
+                                                           float* __restrict__ out_tail, int tail,
+                                                           float gain) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (; i < n4; i += stride) {
+        float4 v = in[i];
+        if (SCALE) { v.x = gain * v.x; v.y = gain * v.y; v.z = gain * v.z; v.w = gain * v.w; }
+        out[i] = v;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail)
+        out_tail[threadIdx.x] = SCALE ? gain * in_tail[threadIdx.x] : in_tail[threadIdx.x];
+}
+
+template <bool SCALE>
+__global__ __launch_bounds__(kBlock) void scale_scalar_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, size_t n,
+                                                             float gain) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (; i < n; i += stride) out[i] = SCALE ? gain * in[i] : in[i];
+}
+
+template <bool SCALE>
+int launch_scale(const float* d_in, float* d_out, size_t n, float gain, hipStream_t s) {
+    if (n == 0) return GAB_OK;
+    if (aligned16(d_in) && aligned16(d_out)) {
+        size_t n4 = n / 4;
+        int tail = (int)(n - 4 * n4);
+        scale_vec4_kernel<SCALE><<<grid_for(n4), kBlock, 0, s>>>(
+            reinterpret_cast<const float4*>(d_in), reinterpret_cast<float4*>(d_out), n4,
+            d_in + 4 * n4, d_out + 4 * n4, tail, gain);
+    } else {
+        scale_scalar_kernel<SCALE><<<grid_for(n), kBlock, 0, s>>>(d_in, d_out, n, gain);
+    }
+    return launch_status(SCALE ? "gain kernel" : "noop kernel");
+}
+
+// ---- gainstats -----------------------------------------------------------------
+// One wavefront per track: coalesced loads, out = gain*in, then a 64-lane
+// butterfly (DPP/ds_swizzle under __shfl_xor) for sum and max.  The sum order
+// differs from the golden's sequential loop; max and the scaled output are exact.
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void gainstats_kernel(const float* __restrict__ in,
+                                                          float* __restrict__ out,
+                                                          float* __restrict__ stats, int T, int B,
+                                                          float gain) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int track = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (track >= T) return;
+    const float* x = in + (size_t)track * B;
+    float* y = out + (size_t)track * B;
+    float sum = 0.0f, mx = -1e9f;
+    if (VEC4) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (int i = lane; i < B / 4; i += kWave) {
+            float4 v = x4[i];
+            sum += (v.x + v.y) + (v.z + v.w);
+            mx = fmaxf(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), mx);
+            y4[i] = make_float4(v.x * gain, v.y * gain, v.z * gain, v.w * gain);
+        }
+    } else {
+        for (int i = lane; i < B; i += kWave) {
+            float v = x[i];
+            sum += v;
+            mx = fmaxf(v, mx);
+            y[i] = v * gain;
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, kWave);
+        mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    }
+    if (lane == 0) {
+        stats[2 * track + 0] = sum / (float)B;
+        stats[2 * track + 1] = mx;
+    }
+}
+
+// ---- datatransfer ----------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void datatransfer_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, int in_size,
+                                                             int out_size) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    const int stride = gridDim.x * kBlock;
+    for (; i < out_size; i += stride)
+        out[i] = (i < in_size) ? in[i] : 0.5f + 0.5f * sinf((float)i * 0.001f);
+}
+
+// ---- modal (placeholder semantics) ---------------------------------------------
+// One workgroup per output row; only params[8*i] of the first out_tracks modes
+// can reach the output in the reference kernel.
+__global__ __launch_bounds__(kBlock) void modal_placeholder_kernel(const float* __restrict__ params,
+                                                                  float* __restrict__ out,
+                                                                  int n_modes, int B) {
+    const int i = blockIdx.x;
+    if (i >= n_modes) return;
+    const float amp = params[(size_t)i * 8 + 0];
+    // Re(exp(0.5 + 0.5i)) = exp(0.5) * cos(0.5)   (cuda/bench_modal.cu:5-13, :24-29)
+    const float value = amp * (expf(0.5f) * cosf(0.5f));
+    for (int s = threadIdx.x; s < B; s += kBlock) out[(size_t)i * B + s] = value;
+}
+
+// ---- rndmem -----------------------------------------------------------------------
+// 64x64 tile: rows = tracks read along the sample axis (256 B per wave load,
+// arbitrary 4-byte alignment since playheads are random), transposed through
+// LDS, written with tracks along the lanes: out[T*i + t].
+__global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict__ pool,
+                                                       const int* __restrict__ playheads,
+                                                       float* __restrict__ out, int T, int B) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (int r = w; r < 64; r += 4) {
+        int t = t0 + r, i = i0 + lane;
+        if (t < T && i < B) tile[r][lane] = pool[(size_t)playheads[t] + i];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = w; r < 64; r += 4) {
+        int i = i0 + r, t = t0 + lane;
+        if (t < T && i < B) out[(size_t)T * i + t] = tile[lane][r];
+    }
+}
+
+}  // namespace
+}  // namespace gab
+
+extern "C" {
+
+int gab_noop(const float* d_in, float* d_out, size_t n, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if ((!d_in || !d_out) && n) return gab::bad_arg("gab_noop: null pointer");
+        return gab::launch_scale<false>(d_in, d_out, n, 1.0f, gab::as_stream(stream));
+    });
+}
+
+int gab_gain(const float* d_in, float* d_out, size_t n, float gain, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if ((!d_in || !d_out) && n) return gab::bad_arg("gab_gain: null pointer");
+        return gab::launch_scale<true>(d_in, d_out, n, gain, gab::as_stream(stream));
+    });
+}
+
+int gab_gainstats(const float* d_in, float* d_out, float* d_stats, int tracks, int bufsize,
+                  float gain, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!d_in || !d_out || !d_stats) return gab::bad_arg("gab_gainstats: null pointer");
+        if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_gainstats: tracks and bufsize must be > 0");
+        const int waves_per_block = gab::kBlock / gab::kWave;
+        dim3 grid((tracks + waves_per_block - 1) / waves_per_block);
+        hipStream_t s = gab::as_stream(stream);
+        if ((bufsize % 4) == 0 && gab::aligned16(d_in) && gab::aligned16(d_out))
+            gab::gainstats_kernel<true><<<grid, gab::kBlock, 0, s>>>(d_in, d_out, d_stats, tracks, bufsize, gain);
+        else
+            gab::gainstats_kernel<false><<<grid, gab::kBlock, 0, s>>>(d_in, d_out, d_stats, tracks, bufsize, gain);
+        return gab::launch_status("gainstats_kernel");
+    });
+}
+
+int gab_datatransfer(const float* d_in, float* d_out, int in_size, int out_size,
+                     gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (in_size < 0 || out_size < 0) return gab::bad_arg("gab_datatransfer: negative size");
+        if (out_size == 0) return GAB_OK;
+        if (!d_out || (!d_in && in_size)) return gab::bad_arg("gab_datatransfer: null pointer");
+        gab::datatransfer_kernel<<<gab::grid_for((size_t)out_size), gab::kBlock, 0, gab::as_stream(stream)>>>(
+            d_in, d_out, in_size, out_size);
+        return gab::launch_status("datatransfer_kernel");
+    });
+}
+
+int gab_modal(const float* d_params, float* d_out, int n_modes, int bufsize, int out_tracks,
+              gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!d_params || !d_out) return gab::bad_arg("gab_modal: null pointer");
+        if (n_modes <= 0 || bufsize <= 0 || out_tracks <= 0) return gab::bad_arg("gab_modal: sizes must be > 0");
+        int rows = n_modes < out_tracks ? n_modes : out_tracks;
+        gab::modal_placeholder_kernel<<<rows, gab::kBlock, 0, gab::as_stream(stream)>>>(
+            d_params, d_out, n_modes, bufsize);
+        return gab::launch_status("modal_placeholder_kernel");
+    });
+}
+
+int gab_rndmem(const float* d_pool, const int* d_playheads, float* d_out, int tracks, int bufsize,
+               gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!d_pool || !d_playheads || !d_out) return gab::bad_arg("gab_rndmem: null pointer");
+        if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_rndmem: tracks and bufsize must be > 0");
+        dim3 grid((bufsize + 63) / 64, (tracks + 63) / 64);
+        gab::rndmem_kernel<<<grid, gab::kBlock, 0, gab::as_stream(stream)>>>(d_pool, d_playheads, d_out,
+                                                                               tracks, bufsize);
+        return gab::launch_status("rndmem_kernel");
+    });
+}
+
+}  // extern "C"

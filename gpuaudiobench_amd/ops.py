@@ -1,0 +1,182 @@
+"""Kernel- and plan-level calls of the C ABI on torch device tensors.
+
+Every function forwards raw device pointers and the current torch stream to
+libgab_hip.so; outputs are allocated with torch (device memory plumbing only).
+Argument names and meaning follow the reference kernels (see gab_c_api.h).
+"""
+import ctypes as C
+
+import torch
+
+from ._capi import (lib, check, WaveguideState, FdtdParams, CONV_STATELESS, CONV_STREAMING,
+                    DWG_NAIVE, DWG_ACCEL)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("expected a CUDA/HIP tensor")
+    if t.dtype != dtype:
+        raise TypeError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib.gab_device_count(C.byref(n)))
+    return n.value
+
+
+def noop(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    check(lib.gab_noop(_dev(x), _dev(out), x.numel(), _stream()))
+    return out
+
+
+def gain(x, g=2.0, out=None):
+    out = torch.empty_like(x) if out is None else out
+    check(lib.gab_gain(_dev(x), _dev(out), x.numel(), g, _stream()))
+    return out
+
+
+def gainstats(x, tracks, bufsize, g=0.5):
+    out = torch.empty_like(x)
+    stats = torch.empty(2 * tracks, dtype=torch.float32, device=x.device)
+    check(lib.gab_gainstats(_dev(x), _dev(out), _dev(stats), tracks, bufsize, g, _stream()))
+    return out, stats
+
+
+def datatransfer(x, out_size):
+    out = torch.empty(out_size, dtype=torch.float32, device=x.device)
+    check(lib.gab_datatransfer(_dev(x) if x.numel() else None, _dev(out) if out_size else None,
+                               x.numel(), out_size, _stream()))
+    return out
+
+
+def iir(x, coeffs, state, tracks, bufsize):
+    """state (tracks*2, device) is updated in place."""
+    out = torch.empty_like(x)
+    c = (C.c_float * 5)(*[float(v) for v in coeffs])
+    check(lib.gab_iir(_dev(x), _dev(out), c, _dev(state), tracks, bufsize, _stream()))
+    return out
+
+
+def conv1d(x, ir, ir_len, tracks, bufsize):
+    out = torch.empty(tracks * bufsize, dtype=torch.float32, device=x.device)
+    check(lib.gab_conv1d(_dev(x), _dev(out), _dev(ir), ir_len, tracks, bufsize, _stream()))
+    return out
+
+
+def rndmem(pool, playheads, tracks, bufsize):
+    out = torch.empty(tracks * bufsize, dtype=torch.float32, device=pool.device)
+    check(lib.gab_rndmem(_dev(pool), _dev(playheads, torch.int32), _dev(out), tracks, bufsize,
+                         _stream()))
+    return out
+
+
+def modal(params, n_modes, bufsize, out_tracks=32):
+    out = torch.zeros(out_tracks * bufsize, dtype=torch.float32, device=params.device)
+    check(lib.gab_modal(_dev(params), _dev(out), n_modes, bufsize, out_tracks, _stream()))
+    return out
+
+
+def dwg(wg_bytes, fwd, bwd, x, bufsize, max_len=2000, out_tracks=None, variant=DWG_ACCEL):
+    """wg_bytes: uint8 device tensor holding n_wg WaveguideState records (32 B each)."""
+    n_wg = wg_bytes.numel() // C.sizeof(WaveguideState)
+    out = torch.empty(bufsize, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.gab_dwg_workspace_bytes(n_wg, bufsize), dtype=torch.uint8, device=x.device)
+    ot = n_wg if out_tracks is None else out_tracks
+    check(lib.gab_dwg(_dev(wg_bytes, torch.uint8), _dev(fwd), _dev(bwd), _dev(x), _dev(out),
+                      _dev(ws, torch.uint8), n_wg, bufsize, max_len, ot, variant, _stream()))
+    return out
+
+
+def fft_r2c_1024(x, tracks):
+    """x: tracks*1024 real -> (tracks, 513, 2) interleaved complex."""
+    out = torch.empty(tracks * 513 * 2, dtype=torch.float32, device=x.device)
+    check(lib.gab_fft_r2c_1024(_dev(x), _dev(out), tracks, _stream()))
+    return out.view(tracks, 513, 2)
+
+
+class ConvPlan:
+    """Conv1DAccelBenchmark's device side: spectra bank + history + process()."""
+
+    def __init__(self, tracks, bufsize, ir_len):
+        self.tracks, self.bufsize, self.ir_len = tracks, bufsize, ir_len
+        self._h = C.c_void_p()
+        check(lib.gab_conv_create(C.byref(self._h), tracks, bufsize, ir_len))
+
+    def set_ir(self, ir):
+        assert ir.numel() == self.tracks * self.ir_len
+        check(lib.gab_conv_set_ir(self._h, _dev(ir), _stream()))
+
+    def reset(self):
+        check(lib.gab_conv_reset(self._h, _stream()))
+
+    def process(self, x, out=None, mode=CONV_STREAMING):
+        assert x.numel() == self.tracks * self.bufsize
+        if out is None:
+            out = torch.empty(self.tracks * self.bufsize, dtype=torch.float32, device=x.device)
+        check(lib.gab_conv_process(self._h, _dev(x), _dev(out), mode, _stream()))
+        return out
+
+    def state_bytes(self):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        check(lib.gab_conv_state_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib.gab_conv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fdtd_default_params(nx, ny=None, nz=None):
+    P = FdtdParams()
+    check(lib.gab_fdtd_default_params(nx, nx if ny is None else ny, nx if nz is None else nz,
+                                      C.byref(P)))
+    return P
+
+
+class FdtdPlan:
+    def __init__(self, params):
+        self.params = params
+        self._h = C.c_void_p()
+        check(lib.gab_fdtd_create(C.byref(self._h), C.byref(params)))
+
+    def reset(self):
+        check(lib.gab_fdtd_reset(self._h, _stream()))
+
+    def process(self, x, out, tracks, bufsize, first_sample, n_samples):
+        check(lib.gab_fdtd_process(self._h, _dev(x), _dev(out), tracks, bufsize, first_sample,
+                                   n_samples, _stream()))
+        return out
+
+    def pressure(self):
+        """A copy of the pressure grid as a torch tensor (nz, ny, nx)."""
+        P = self.params
+        out = torch.empty(P.nx * P.ny * P.nz, dtype=torch.float32, device="cuda")
+        check(lib.gab_fdtd_copy_pressure(self._h, _dev(out), _stream()))
+        return out.view(P.nz, P.ny, P.nx)
+
+    def close(self):
+        if self._h:
+            lib.gab_fdtd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

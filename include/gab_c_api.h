@@ -1,0 +1,209 @@
+/*
+ * gab_c_api.h — C ABI of libgab_hip.so, the MI355X (gfx950) implementation of
+ * the gpuaudiobench hot path.
+ *
+ * The reference (tskare/gpuaudiobench, cuda/) has no FFI of its own: its
+ * boundary is the C++ class GPUABenchmark (cuda/bench_base.cuh:18-139) plus one
+ * __global__ kernel (or cuFFT pipeline) per benchmark.  This header is what a
+ * binding for that path would import:
+ *   - section K: one entry point per reference kernel / vendor-library call
+ *     site, taking DEVICE pointers, sizes and a HIP stream;
+ *   - section P: plan objects for the two stateful pipelines (FFT convolution,
+ *     FDTD3D);
+ *   - section H: the harness itself (create/setup/run/validate by registry
+ *     name), mirroring main.cu's runSelectedBenchmark (cuda/main.cu:117-164).
+ * C++ users include include/gab/ *.hpp instead and get the reference's class
+ * surface directly.
+ *
+ * Conventions: plain pointers and sizes only; every function returns GAB_OK (0),
+ * a positive hipError_t value, or a negative GAB_ERR_*; no exception crosses
+ * this boundary (gab_last_error() holds the text, thread-local).  All kernels
+ * are asynchronous on `stream` (a hipStream_t cast to void*; NULL = default
+ * stream) unless stated otherwise.  Layouts follow the reference:
+ * "track-major" = [t*B + s], "sample-major" = [T*s + t].
+ */
+#ifndef GAB_C_API_H
+#define GAB_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAB_OK 0
+#define GAB_ERR_INVALID_ARG (-1)
+#define GAB_ERR_RUNTIME     (-2)
+#define GAB_ERR_UNSUPPORTED (-3)
+
+typedef void* gab_stream_t;
+
+int         gab_version(void);            /* 10000*major + 100*minor + patch   */
+const char* gab_last_error(void);
+int         gab_device_count(int* count); /* cuda/main.cu:307-314              */
+
+/* ===================================================================== */
+/* K. kernels                                                            */
+/* ===================================================================== */
+
+/* NoOpKernel (cuda/bench_noop.cu:9-16): out[i] = in[i], i < n.  (The
+ * reference launch covers only ceil(T/256)*256 elements; this copies all n.) */
+int gab_noop(const float* d_in, float* d_out, size_t n, gab_stream_t stream);
+
+/* GainKernel (cuda/bench_gain.cu:6-24): out[i] = gain * in[i].  Bit-exact.   */
+int gab_gain(const float* d_in, float* d_out, size_t n, float gain,
+             gab_stream_t stream);
+
+/* GainStatsKernel (cuda/bench_gainstats.cu:7-31): out = gain*in (track-major
+ * T x B); stats[2t] = mean of the INPUT track, stats[2t+1] = max (from -1e9). */
+int gab_gainstats(const float* d_in, float* d_out, float* d_stats, int tracks,
+                  int bufsize, float gain, gab_stream_t stream);
+
+/* DataTransferKernel (cuda/bench_datatransfer.cu:15-25):
+ * out[i] = i < in_size ? in[i] : 0.5f + 0.5f*sinf(0.001f*i), i < out_size.    */
+int gab_datatransfer(const float* d_in, float* d_out, int in_size, int out_size,
+                     gab_stream_t stream);
+
+/* IIRFilterKernel (cuda/bench_iir.cu:10-44): DF-II biquad per track,
+ * coeffs = {b0,b1,b2,a1,a2} (HOST pointer, 5 floats), d_state = T x {z1,z2}
+ * read and written back.  Same operation order as the golden: bit-exact.     */
+int gab_iir(const float* d_in, float* d_out, const float* coeffs,
+            float* d_state, int tracks, int bufsize, gab_stream_t stream);
+
+/* Conv1DTextureMemoryImplKernel (cuda/bench_conv1d.cu:7-27) with the CPU
+ * golden's semantics (:188-208): y[t*B+i] = sum_j h[t*L+j] * x_flat[t*B+i-j]
+ * over the FLAT input (history = previous track), j ascending.  d_ir is
+ * T x L track-major (replaces the 2-D texture).                              */
+int gab_conv1d(const float* d_in, float* d_out, const float* d_ir, int ir_len,
+               int tracks, int bufsize, gab_stream_t stream);
+
+/* RndMemKernel (cuda/bench_rndmem.cu:7-20): out[T*i+t] = pool[playhead[t]+i].
+ * pool_elems is used to range-check nothing on device; it is the caller's
+ * promise that playhead[t]+bufsize <= pool_elems.  Bit-exact copy.           */
+int gab_rndmem(const float* d_pool, const int* d_playheads, float* d_out,
+               int tracks, int bufsize, gab_stream_t stream);
+
+/* ModalSynthesisKernel (cuda/bench_modal.cu:15-36), placeholder semantics:
+ * out[i*B+s] = params[8i+0] * Re(exp(0.5+0.5i)) for i < out_tracks.           */
+int gab_modal(const float* d_params, float* d_out, int n_modes, int bufsize,
+              int out_tracks, gab_stream_t stream);
+
+/* WaveguideState (cuda/bench_dwg.cuh:19-28), 32 bytes.                       */
+typedef struct {
+    int   length, inputTapPos, outputTapPos, writePos;
+    float gain, reflection, damping, padding;
+} gab_waveguide_state;
+
+#define GAB_DWG_NAIVE 0   /* DWG1DNaiveKernel (cuda/bench_dwg.cu:10-59)       */
+#define GAB_DWG_ACCEL 1   /* DWG1DAccelKernel (cuda/bench_dwg.cu:61-141)      */
+/* Workspace the ordered (atomic-free) output reduction needs, in bytes.      */
+size_t gab_dwg_workspace_bytes(int n_waveguides, int bufsize);
+/* Updates the two delay-line banks (n_wg x max_len) in place and writes the
+ * mono mix d_out[bufsize], summed over waveguides in index order.            */
+int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd,
+            const float* d_in, float* d_out, void* d_workspace, int n_waveguides,
+            int bufsize, int max_len, int out_tracks, int variant,
+            gab_stream_t stream);
+
+/* cufftExecR2C, N=1024, batch = tracks (cuda/bench_fft.cu:63,105):
+ * d_in tracks x 1024 real, d_out tracks x 513 interleaved complex.           */
+int gab_fft_r2c_1024(const float* d_in, float* d_out, int tracks,
+                     gab_stream_t stream);
+
+/* ===================================================================== */
+/* P. plans                                                              */
+/* ===================================================================== */
+
+/* ---- FFT convolution (Conv1DAccelBenchmark, cuda/bench_conv1d_accel.cu) -- */
+typedef struct gab_conv_plan gab_conv_plan;
+
+#define GAB_CONV_STATELESS 0  /* reference semantics: zero history each call  */
+#define GAB_CONV_STREAMING 1  /* overlap-save with carried history            */
+
+/* allocateAccelBuffers + setupFFTPlans (:88-150).  Allocates the spectra bank
+ * and the history ring on the current device.                                */
+int gab_conv_create(gab_conv_plan** plan, int tracks, int bufsize, int ir_len);
+int gab_conv_destroy(gab_conv_plan* plan);
+/* precomputeImpulseResponseFFTs (:175-228): d_ir is tracks x ir_len floats on
+ * the device.  Synchronous with respect to `stream`.                         */
+int gab_conv_set_ir(gab_conv_plan* plan, const float* d_ir, gab_stream_t stream);
+/* Forget all history (the state a freshly created plan has).                 */
+int gab_conv_reset(gab_conv_plan* plan, gab_stream_t stream);
+/* One buffer: d_in track-major T x B, d_out sample-major [T*s+t]
+ * (performBenchmarkIteration :258-304 without the host copies).              */
+int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
+                     int mode, gab_stream_t stream);
+/* Bytes of device state the plan holds: spectra, history.                    */
+int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
+                         size_t* history_bytes);
+
+/* ---- FDTD3D (FDTD3DBenchmark, cuda/bench_fdtd3d.cu) ---------------------- */
+typedef struct gab_fdtd_plan gab_fdtd_plan;
+
+/* FDTD3DParams (cuda/bench_fdtd3d.cuh:68-86), the fields the kernels read.   */
+typedef struct {
+    int   nx, ny, nz;
+    int   source_x, source_y, source_z;
+    int   receiver_x, receiver_y, receiver_z;
+    int   steps_per_sample;
+    float dt_over_rho_dx, rho_c2_dt_over_dx, absorption_coeff;
+} gab_fdtd_params;
+
+/* Reference constants (bench_fdtd3d.cuh:12-41) for an nx*ny*nz grid; source
+ * and receiver scale with the room so 52^3 gives (25,25,5)/(40,15,25).       */
+int gab_fdtd_default_params(int nx, int ny, int nz, gab_fdtd_params* out);
+int gab_fdtd_create(gab_fdtd_plan** plan, const gab_fdtd_params* params);
+int gab_fdtd_destroy(gab_fdtd_plan* plan);
+int gab_fdtd_reset(gab_fdtd_plan* plan, gab_stream_t stream);     /* zero grids */
+/* runFDTD3DTimeStep (:384-438) for samples [first_sample, first_sample+n):
+ * inject -> steps_per_sample x {velocity, pressure} -> extract.
+ * d_in/d_out are track-major T x B.                                          */
+int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
+                     int tracks, int bufsize, int first_sample, int n_samples,
+                     gab_stream_t stream);
+/* Copy the current pressure grid (nx*ny*nz floats, x fastest) to d_dst.      */
+int gab_fdtd_copy_pressure(gab_fdtd_plan* plan, float* d_dst, gab_stream_t stream);
+
+/* ===================================================================== */
+/* H. harness (GPUABenchmark by registry name)                           */
+/* ===================================================================== */
+
+typedef struct gab_bench gab_bench;
+
+typedef struct {
+    int    fs, buffer_size, n_tracks, n_runs;       /* cuda/globals.cu:4-7     */
+    int    ir_length;       /* <=0: the benchmark's DEFAULT_IR_LEN             */
+    int    fdtd_grid;       /* <=0: 52 (bench_fdtd3d.cuh:36-38)                */
+    int    conv_mode;       /* GAB_CONV_*                                      */
+    int    quiet;           /* suppress the reference's progress printf        */
+} gab_bench_config;
+
+typedef struct {
+    int    iterations;
+    float  mean_ms, median_ms, std_dev_ms, min_ms, max_ms, p95_ms, p99_ms;
+    float  gpu_median_ms;                    /* 0 when the benchmark records none */
+    double throughput_gbps, samples_per_sec; /* cuda/bench_base.cu:110-115     */
+    size_t bytes_processed;
+} gab_bench_result;
+
+typedef struct {
+    int   status;            /* 0 SUCCESS, 1 FAILURE, -1 FATAL (bench_base.cuh:36-40) */
+    float max_error, mean_error;
+} gab_bench_validation;
+
+void gab_bench_default_config(gab_bench_config* cfg);
+int  gab_bench_count(void);
+const char* gab_bench_name(int index);                 /* cuda/main.cu:84-100 */
+int  gab_bench_create(gab_bench** b, const char* name, const gab_bench_config* cfg);
+int  gab_bench_destroy(gab_bench* b);
+int  gab_bench_setup(gab_bench* b);
+int  gab_bench_run(gab_bench* b, int iterations, int warmup, gab_bench_result* out);
+int  gab_bench_validate(gab_bench* b, gab_bench_validation* out);
+/* latencies of the last run (ms); returns how many were copied               */
+int  gab_bench_latencies(gab_bench* b, float* out, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAB_C_API_H */
