@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: streaming 4096-tap FIR convolution
+(bench_conv1d_accel) x 1024 channels x 512-sample buffers @ 48 kHz on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one audio buffer (512 new samples for every one of a rank's 1024
+channels) pushed through the fused overlap-save kernel with carried history.
+Inputs are resident in HBM before the timed region.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank owns a 1024-channel shard
+of an N*1024-channel job: rank 0 generates the whole impulse-response bank, it
+is broadcast over RCCL/xGMI once, each rank transforms its slice; there is no
+per-buffer collective (channels are independent), so scaling is weak.
+
+One JSON line on rank 0:
+  value      = 1024-channel buffers per second, whole job (N * K / max-rank time)
+  roofline   = algorithmic bytes per launch / average kernel duration (HIP events
+               on the launch stream), against the 8 TB/s HBM peak
+  cpu_baseline = the CPU oracle (reference golden extended with history), one
+               core, timed on a bounded sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TRACKS_PER_GPU = 1024
+BUFSIZE = 512
+TAPS = 4096
+FS = 48000
+N_INPUT_BUFFERS = 16            # distinct input buffers cycled through (32 MiB of HBM)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(tracks, bufsize, taps):
+    # new input + output + every tap + every history sample the taps reach
+    return 4 * tracks * (2 * bufsize + 2 * taps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--roundtrip-iters", type=int, default=300)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import gpuaudiobench_amd as gab           # raises if libgab_hip.so is missing
+
+    T, B, L = TRACKS_PER_GPU, BUFSIZE, TAPS
+    T_total = T * world
+
+    # ---- impulse-response bank: generated once, broadcast over RCCL -------------
+    if world > 1:
+        bank = torch.empty(T_total * L, dtype=torch.float32, device=dev)
+        if rank == 0:
+            bank.copy_(torch.from_numpy(gab.harness.conv_accel_ir(L, T_total)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(bank, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+        ir_dev = bank.view(T_total, L)[rank * T:(rank + 1) * T].contiguous()
+        del bank
+    else:
+        bcast_ms = None
+        ir_dev = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).to(dev)
+
+    plan = gab.ConvPlan(T, B, L)
+    plan.set_ir(ir_dev)
+    spectra_bytes, history_bytes = plan.state_bytes()
+
+    # ---- synthetic input: the reference's noise generator, this rank's channels --
+    inputs = []
+    for i in range(N_INPUT_BUFFERS):
+        flat = gab.harness.noise(T_total * B, seed=42 + i)       # flat track-major order
+        inputs.append(torch.from_numpy(flat.reshape(T_total, B)[rank * T:(rank + 1) * T].copy()).to(dev))
+    out = torch.empty(T * B, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        plan.process(inputs[i % N_INPUT_BUFFERS], out=out, mode=gab.CONV_STREAMING)
+
+    for i in range(args.warmup):
+        step(i)
+
+    # ---- timed region -------------------------------------------------------------
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)                 # device view of the same K launches
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-launch kernel duration: one event pair per launch (outside `value`) ---
+    n_pairs = min(args.steps, 400)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(n_pairs)]
+    for i, (a, b) in enumerate(pairs):
+        a.record(stream)
+        step(i)
+        b.record(stream)
+    torch.cuda.synchronize()
+    kernel_us = float(np.mean([a.elapsed_time(b) for a, b in pairs]) * 1e3)
+    period_us = region_ms * 1e3 / args.steps
+
+    # ---- p50 round trip: pinned host -> HBM -> kernel -> HBM -> pinned host ----------
+    h_in = torch.from_numpy(gab.harness.noise(T * B, seed=7)).pin_memory()
+    h_out = torch.empty(T * B, dtype=torch.float32).pin_memory()
+    d_in = torch.empty(T * B, dtype=torch.float32, device=dev)
+    rt = []
+    for i in range(args.roundtrip_iters + 20):
+        t1 = time.perf_counter()
+        d_in.copy_(h_in, non_blocking=True)
+        plan.process(d_in, out=out, mode=gab.CONV_STREAMING)
+        h_out.copy_(out, non_blocking=True)
+        stream.synchronize()
+        if i >= 20:
+            rt.append((time.perf_counter() - t1) * 1e6)
+    rt = np.array(rt)
+
+    alg = algorithmic_bytes(T, B, L)
+    # achieved is priced on the launch period of the timed region (kernel time plus
+    # the inter-launch gap): that is what back-to-back buffers actually cost.
+    achieved = alg / (period_us * 1e-6) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("conv_overlap_save_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "audio_buffers_per_sec",
+        "value": world * args.steps / elapsed,
+        "unit": "buffers/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "bench_conv1d_accel streaming overlap-save: %d-tap IR x %d channels x "
+                        "%d-sample buffers @ %d Hz per GPU (BASELINE configs[2]%s)"
+                        % (L, T, B, FS, "; configs[4]-style channel sharding, %d channels total" % T_total
+                           if world > 1 else ""),
+            "taps": L, "channels_per_gpu": T, "channels_total": T_total, "buffer_size": B, "fs": FS,
+            "mode": "streaming",
+            "realtime_factor": (world * args.steps / elapsed) * B / FS,
+            "p50_round_trip_us": float(np.percentile(rt, 50)),
+            "p95_round_trip_us": float(np.percentile(rt, 95)),
+            "ir_broadcast_ms": bcast_ms,
+            "state_bytes": {"spectra": spectra_bytes, "history": history_bytes},
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "conv_overlap_save_kernel<true,true>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg,
+            "launch_period_us": period_us,
+            "kernel_us_event_pairs": kernel_us,
+        },
+    }
+
+    # ---- CPU baseline: the oracle, one core, bounded sample (rank 0, N = 1) ------------
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        import oracle                     # checker / baseline only — never the product path
+        ir_host = ir_dev.cpu().numpy().ravel()
+        hist = np.zeros(T * L, np.float32)
+        x = inputs[0].cpu().numpy().ravel()
+        t1 = time.perf_counter()
+        oracle.conv_accel_stream(x, ir_host, hist, L, B, T)
+        first = time.perf_counter() - t1
+        n_more = max(1, min(20, int(args.cpu_baseline_seconds / first) - 1))
+        t1 = time.perf_counter()
+        for i in range(n_more):
+            oracle.conv_accel_stream(inputs[(i + 1) % N_INPUT_BUFFERS].cpu().numpy().ravel(),
+                                     ir_host, hist, L, B, T)
+        dt = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": n_more / dt,
+            "unit": "buffers/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "%d buffers of the full %d-channel x %d-tap workload, direct-form fp32 "
+                      "(oracle/gab_oracle.c orc_conv_accel_stream), %.1f s" % (n_more, T, L, dt),
+        }
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

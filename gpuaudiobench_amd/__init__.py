@@ -11,7 +11,11 @@ from ._capi import GabError, lib, check, CONV_STATELESS, CONV_STREAMING, DWG_NAI
 from .ops import (noop, gain, gainstats, datatransfer, iir, conv1d, rndmem, modal, dwg,
                   fft_r2c_1024, ConvPlan, FdtdPlan, fdtd_default_params, device_count)
 
+from . import harness
+from .harness import Benchmark, benchmark_names
+
 __all__ = [
+    "harness", "Benchmark", "benchmark_names",
     "GabError", "lib", "check", "CONV_STATELESS", "CONV_STREAMING", "DWG_NAIVE", "DWG_ACCEL",
     "noop", "gain", "gainstats", "datatransfer", "iir", "conv1d", "rndmem", "modal", "dwg",
     "fft_r2c_1024", "ConvPlan", "FdtdPlan", "fdtd_default_params", "device_count",

@@ -51,6 +51,11 @@ class BenchResult(C.Structure):
                              ("bytes_processed", C.c_size_t)]
 
 
+class Statistics(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "mean", "median", "std_dev", "min_val", "max_val", "p95", "p99")] + [("count", C.c_size_t)]
+
+
 class BenchValidation(C.Structure):
     _fields_ = [("status", C.c_int), ("max_error", C.c_float), ("mean_error", C.c_float)]
 
@@ -89,6 +94,24 @@ PROTOTYPES = {
     "gab_fdtd_reset": (_I, [_P, _P]),
     "gab_fdtd_process": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "gab_fdtd_copy_pressure": (_I, [_P, _P, _P]),
+    "gab_generate_noise": (_I, [_P, _Z, C.c_uint]),
+    "gab_generate_conv1d_ir": (_I, [_P, _I, _Z, _Z, _Z]),
+    "gab_generate_conv_accel_ir": (_I, [_P, _I, _Z, _Z, _Z]),
+    "gab_calculate_statistics": (_I, [_P, _Z, C.POINTER(Statistics)]),
+    "gab_set_globals": (_I, [_I, _I, _I, _I]),
+    "gab_format_json_results": (_Z, [_P, _Z, C.c_char_p, C.c_char_p, _Z]),
+    "gab_write_csv_results": (_I, [_P, _Z, C.c_char_p, C.c_char_p]),
+    "gab_bench_default_config": (None, [C.POINTER(BenchConfig)]),
+    "gab_bench_count": (_I, []),
+    "gab_bench_name": (C.c_char_p, [_I]),
+    "gab_bench_create": (_I, [C.POINTER(_P), C.c_char_p, C.POINTER(BenchConfig)]),
+    "gab_bench_destroy": (_I, [_P]),
+    "gab_bench_setup": (_I, [_P]),
+    "gab_bench_run": (_I, [_P, _I, _I, C.POINTER(BenchResult)]),
+    "gab_bench_validate": (_I, [_P, C.POINTER(BenchValidation)]),
+    "gab_bench_latencies": (_I, [_P, C.POINTER(_F), _I]),
+    "gab_bench_validation_text": (C.c_char_p, [_P]),
+    "gab_bench_algorithmic_bytes": (_I, [_P, C.POINTER(_Z)]),
 }
 
 

@@ -1,0 +1,990 @@
+// h_benchmarks.cpp — the benchmark classes and the name registry.
+//
+// Host orchestration only: every device result comes from the HIP kernels
+// behind the C ABI (gab_*).  Iteration shape follows the reference
+// (H2D -> kernel(s) -> D2H per iteration) but on the benchmark's own stream with
+// pinned buffers, and persistent signal state (IIR z1/z2, delay lines, FDTD
+// grids, convolution history) stays resident on the device between iterations.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+#include "gab/benchmarks.hpp"
+#include "h_golden.hpp"
+
+using BenchmarkUtils::allocateDeviceBuffer;
+using BenchmarkUtils::allocateHostBuffer;
+using BenchmarkUtils::freeDeviceBuffers;
+using BenchmarkUtils::freeHostBuffers;
+
+namespace {
+
+// Runs `enqueue` on the stream between two events and returns device ms.
+struct ScopedGpuTimer {
+    BenchmarkUtils::HipEventTimer t;
+    hipStream_t s;
+    explicit ScopedGpuTimer(hipStream_t stream) : s(stream) { t.start(s); }
+    float finish() { return t.stop(s); }
+};
+
+float peak_abs(const float* a, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = std::max(m, std::abs(a[i]));
+    return m;
+}
+
+float max_abs_diff(const float* a, const float* b, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float d = std::abs(a[i] - b[i]);
+        if (d > m || std::isnan(d)) m = std::isnan(d) ? INFINITY : d;
+    }
+    return m;
+}
+
+void say(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void say(const char* fmt, ...) {
+    if (GAB_QUIET) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vprintf(fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace
+
+// ===========================================================================
+// NoOp
+// ===========================================================================
+NoOpBenchmark::NoOpBenchmark(size_t buffer_size, size_t track_count)
+    : GPUABenchmark("NoOp", buffer_size, track_count) {}
+
+NoOpBenchmark::~NoOpBenchmark() { freeHostBuffers({cpu_reference}); }
+
+void NoOpBenchmark::setupBenchmark() {
+    allocateBuffers(getTotalElements());
+    generateTestData(42);
+    cpu_reference = allocateHostBuffer<float>(getTotalElements(), "noop cpu reference");
+    std::memcpy(cpu_reference, getHostInput(), getTotalElements() * sizeof(float));
+    say("NoOp benchmark setup complete (measuring kernel launch overhead)\n");
+}
+
+void NoOpBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void NoOpBenchmark::performBenchmarkIteration() {
+    transferToDevice();
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_noop(getDeviceInput(), getDeviceOutput(), getTotalElements(), stream_), "gab_noop");
+    recordGpuDuration(g.finish());
+    transferToHost();
+}
+
+void NoOpBenchmark::validate(ValidationData& v) {
+    v = compareWithReference(cpu_reference, 1e-5f);
+    if (v.status == ValidationStatus::SUCCESS) v.messages.push_back("NoOp validation passed");
+}
+
+// ===========================================================================
+// Gain
+// ===========================================================================
+GainBenchmark::GainBenchmark(size_t buffer_size, size_t track_count, bool enable_validation)
+    : GPUABenchmark("Gain", buffer_size, track_count), enable_validation_(enable_validation) {}
+
+GainBenchmark::~GainBenchmark() { freeHostBuffers({cpu_reference}); }
+
+void GainBenchmark::setupBenchmark() {
+    allocateBuffers(getTotalElements());
+    generateTestData(42);
+    if (enable_validation_) {
+        cpu_reference = allocateHostBuffer<float>(getTotalElements(), "gain cpu reference");
+        gab::golden::gain(getHostInput(), cpu_reference, getTotalElements(), BenchmarkConstants::GAIN_VALUE);
+    }
+    say("Gain benchmark setup complete (gain = %.1f)\n", BenchmarkConstants::GAIN_VALUE);
+}
+
+void GainBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void GainBenchmark::performBenchmarkIteration() {
+    transferToDevice();
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_gain(getDeviceInput(), getDeviceOutput(), getTotalElements(),
+                      BenchmarkConstants::GAIN_VALUE, stream_), "gab_gain");
+    recordGpuDuration(g.finish());
+    transferToHost();
+}
+
+void GainBenchmark::validate(ValidationData& v) {
+    if (!enable_validation_) {
+        v.status = ValidationStatus::SUCCESS;
+        v.messages.push_back("Validation skipped (disabled)");
+        return;
+    }
+    v = compareWithReference(cpu_reference, 1e-5f);
+    if (v.status == ValidationStatus::SUCCESS) v.messages.push_back("Gain validation passed");
+}
+
+// ===========================================================================
+// GainStats
+// ===========================================================================
+GainStatsBenchmark::GainStatsBenchmark(size_t buffer_size, size_t track_count)
+    : GPUABenchmark("GainStats", buffer_size, track_count) {
+    stats_count = track_count * NSTATS;
+    stats_size_bytes = stats_count * sizeof(float);
+}
+
+GainStatsBenchmark::~GainStatsBenchmark() {
+    freeHostBuffers({h_stats, cpu_reference, cpu_stats_reference});
+    freeDeviceBuffers({d_stats});
+}
+
+void GainStatsBenchmark::setupBenchmark() {
+    allocateBuffers(getTotalElements());
+    h_stats = allocateHostBuffer<float>(stats_count, benchmark_name_ + " host stats buffer");
+    d_stats = allocateDeviceBuffer<float>(stats_count, benchmark_name_ + " device stats buffer");
+    std::memset(h_stats, 0, stats_size_bytes);
+    generateTestData(42);
+    cpu_reference = allocateHostBuffer<float>(getTotalElements(), "gainstats cpu reference");
+    cpu_stats_reference = allocateHostBuffer<float>(stats_count, "gainstats cpu stats reference");
+    gab::golden::gainstats(getHostInput(), cpu_reference, cpu_stats_reference, getTrackCount(), getBufferSize());
+    say("GainStats benchmark setup complete (gain = %.1f, computing mean + max per track)\n",
+        BenchmarkConstants::GAINSTATS_GAIN);
+}
+
+void GainStatsBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void GainStatsBenchmark::performBenchmarkIteration() {
+    transferToDevice();
+    ScopedGpuTimer g(stream_);
+    // every stats slot is written by the kernel: no per-iteration memset needed
+    checkGab(gab_gainstats(getDeviceInput(), getDeviceOutput(), d_stats, static_cast<int>(getTrackCount()),
+                           static_cast<int>(getBufferSize()), BenchmarkConstants::GAINSTATS_GAIN, stream_),
+             "gab_gainstats");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, stats_size_bytes, hipMemcpyDeviceToHost, stream_));
+    transferToHost();
+}
+
+void GainStatsBenchmark::validate(ValidationData& v) {
+    v = compareWithReference(cpu_reference, 1e-5f);
+    float mx = 0.0f;
+    for (size_t i = 0; i < stats_count; ++i) mx = std::max(mx, std::abs(h_stats[i] - cpu_stats_reference[i]));
+    if (mx > 1e-4f) {
+        v.status = ValidationStatus::FAILURE;
+        v.messages.push_back("Statistics validation failed");
+        v.max_error = std::max(v.max_error, mx);
+    } else if (v.status == ValidationStatus::SUCCESS) {
+        v.messages.push_back("GainStats validation passed (output + statistics)");
+    }
+}
+
+size_t GainStatsBenchmark::algorithmicBytes() const {
+    return 2 * getTotalElements() * sizeof(float) + stats_size_bytes;
+}
+
+// ===========================================================================
+// DataTransfer
+// ===========================================================================
+const DataTransferBenchmark::Config DataTransferBenchmark::CONFIGS[] = {
+    {0.01f, 0.99f, "datacopy0199"}, {0.20f, 0.80f, "datacopy2080"}, {0.50f, 0.50f, "datacopy5050"},
+    {0.80f, 0.20f, "datacopy8020"}, {0.99f, 0.01f, "datacopy9901"}};
+const int DataTransferBenchmark::NUM_CONFIGS = sizeof(CONFIGS) / sizeof(CONFIGS[0]);
+
+DataTransferBenchmark::DataTransferBenchmark(const Config& config)
+    : GPUABenchmark(config.name, 1, 1), config_(config) {
+    input_size = static_cast<int>(BASE_BUFFER_SIZE * config_.inputRatio);
+    output_size = static_cast<int>(BASE_BUFFER_SIZE * config_.outputRatio);
+    input_size_bytes = input_size * sizeof(float);
+    output_size_bytes = output_size * sizeof(float);
+}
+
+DataTransferBenchmark::DataTransferBenchmark(float input_ratio, float output_ratio, const char* name)
+    : DataTransferBenchmark(Config{input_ratio, output_ratio, name}) {}
+
+DataTransferBenchmark::~DataTransferBenchmark() {
+    freeHostBuffers({h_input_var, h_output_var, cpu_reference});
+    freeDeviceBuffers({d_input_var, d_output_var});
+}
+
+DataTransferBenchmark* DataTransferBenchmark::createFromName(const std::string& name) {
+    for (int i = 0; i < NUM_CONFIGS; ++i)
+        if (name == CONFIGS[i].name) return new DataTransferBenchmark(CONFIGS[i]);
+    return nullptr;
+}
+
+void DataTransferBenchmark::setupBenchmark() {
+    const std::string n(config_.name);
+    h_input_var = allocateHostBuffer<float>(input_size, n + " host input buffer");
+    h_output_var = allocateHostBuffer<float>(output_size, n + " host output buffer");
+    d_input_var = allocateDeviceBuffer<float>(input_size, n + " device input buffer");
+    d_output_var = allocateDeviceBuffer<float>(output_size, n + " device output buffer");
+    std::memset(h_output_var, 0, output_size_bytes);
+    cpu_reference = allocateHostBuffer<float>(output_size, n + " cpu reference");
+    for (int i = 0; i < input_size; ++i)
+        h_input_var[i] = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+    gab::golden::datatransfer(h_input_var, cpu_reference, input_size, output_size);
+    say("DataTransfer %s setup complete - Input: %d floats (%.1f%%), Output: %d floats (%.1f%%)\n",
+        config_.name, input_size, config_.inputRatio * 100.0f, output_size, config_.outputRatio * 100.0f);
+}
+
+void DataTransferBenchmark::runKernel() { performBenchmarkIteration(); }
+
+// pinned hipHostMalloc buffers + hipMemcpyAsync: H2D, kernel and D2H are queued
+// back to back on one stream; the host blocks once, at the end.
+void DataTransferBenchmark::performBenchmarkIteration() {
+    HIP_CHECK(hipMemcpyAsync(d_input_var, h_input_var, input_size_bytes, hipMemcpyHostToDevice, stream_));
+    checkGab(gab_datatransfer(d_input_var, d_output_var, input_size, output_size, stream_), "gab_datatransfer");
+    HIP_CHECK(hipMemcpyAsync(h_output_var, d_output_var, output_size_bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DataTransferBenchmark::validate(ValidationData& v) {
+    v = compareArrays(h_output_var, cpu_reference, output_size, 1e-5f);
+    v.messages.clear();
+    v.messages.push_back(v.status == ValidationStatus::SUCCESS ? "DataTransfer validation passed"
+                                                               : "DataTransfer validation failed");
+}
+
+size_t DataTransferBenchmark::algorithmicBytes() const { return input_size_bytes + output_size_bytes; }
+
+// ===========================================================================
+// FFT1D
+// ===========================================================================
+FFTBenchmark::FFTBenchmark(size_t buffer_size, size_t track_count)
+    : GPUABenchmark("FFT1D", buffer_size, track_count) {
+    input_fft_size = track_count * FFT_SIZE;
+    output_fft_size = track_count * (FFT_SIZE / 2 + 1);
+    input_fft_bytes = input_fft_size * sizeof(float);
+    output_fft_bytes = output_fft_size * sizeof(float2);
+}
+
+FFTBenchmark::~FFTBenchmark() {
+    freeHostBuffers({h_input_fft, h_output_fft, cpu_reference_real, cpu_reference_imag});
+    freeDeviceBuffers({d_input_fft, d_output_fft});
+}
+
+void FFTBenchmark::setupBenchmark() {
+    h_input_fft = allocateHostBuffer<float>(input_fft_size, benchmark_name_ + " host input FFT buffer");
+    h_output_fft = allocateHostBuffer<float2>(output_fft_size, benchmark_name_ + " host output FFT buffer");
+    d_input_fft = allocateDeviceBuffer<float>(input_fft_size, benchmark_name_ + " device input FFT buffer");
+    d_output_fft = allocateDeviceBuffer<float2>(output_fft_size, benchmark_name_ + " device output FFT buffer");
+    std::memset(h_output_fft, 0, output_fft_bytes);
+
+    const size_t per_track = std::min(getBufferSize(), static_cast<size_t>(FFT_SIZE));
+    for (size_t t = 0; t < getTrackCount(); ++t) {
+        for (size_t i = 0; i < per_track; ++i)
+            h_input_fft[t * FFT_SIZE + i] = ((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f;
+        for (size_t i = per_track; i < FFT_SIZE; ++i) h_input_fft[t * FFT_SIZE + i] = 0.0f;
+    }
+    cpu_reference_real = allocateHostBuffer<float>(output_fft_size, "fft cpu reference real");
+    cpu_reference_imag = allocateHostBuffer<float>(output_fft_size, "fft cpu reference imag");
+    gab::golden::dft1024(h_input_fft, cpu_reference_real, cpu_reference_imag, getTrackCount());
+    say("FFT benchmark setup complete (FFT size = %d, %zu tracks)\n", FFT_SIZE, getTrackCount());
+}
+
+void FFTBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void FFTBenchmark::performBenchmarkIteration() {
+    HIP_CHECK(hipMemcpyAsync(d_input_fft, h_input_fft, input_fft_bytes, hipMemcpyHostToDevice, stream_));
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_fft_r2c_1024(d_input_fft, reinterpret_cast<float*>(d_output_fft),
+                              static_cast<int>(getTrackCount()), stream_), "gab_fft_r2c_1024");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_output_fft, d_output_fft, output_fft_bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// The reference gate (|dre|+|dim| <= 1e-3 against its fp32 naive DFT) cannot be
+// met by a correct transform: that golden is itself ~3e-3 from the true DFT
+// (fp32 angles up to 3.2e3 rad).  Gate: <= 1e-5 of the spectrum's peak against a
+// float64 DFT, and not further from it than the reference golden is.
+void FFTBenchmark::validate(ValidationData& v) {
+    std::vector<double> tr(output_fft_size), ti(output_fft_size);
+    gab::golden::dft1024_f64(h_input_fft, tr.data(), ti.data(), getTrackCount());
+    double peak = 0.0, e_out = 0.0, e_gold = 0.0, own = 0.0, sum = 0.0;
+    for (size_t i = 0; i < output_fft_size; ++i) {
+        peak = std::max(peak, std::sqrt(tr[i] * tr[i] + ti[i] * ti[i]));
+        double eo = std::abs(h_output_fft[i].x - tr[i]) + std::abs(h_output_fft[i].y - ti[i]);
+        double eg = std::abs(cpu_reference_real[i] - tr[i]) + std::abs(cpu_reference_imag[i] - ti[i]);
+        double ref_metric = std::abs(h_output_fft[i].x - cpu_reference_real[i]) +
+                            std::abs(h_output_fft[i].y - cpu_reference_imag[i]);
+        e_out = std::max(e_out, eo);
+        e_gold = std::max(e_gold, eg);
+        own = std::max(own, ref_metric);
+        sum += ref_metric;
+    }
+    err_out_vs_truth_ = e_out;
+    err_golden_vs_truth_ = e_gold;
+    v.max_error = static_cast<float>(own);                       // the reference's metric, reported
+    v.mean_error = static_cast<float>(sum / (2.0 * output_fft_size));
+    const bool ok = (e_out <= 1e-5 * peak) && (e_out <= e_gold);
+    v.status = ok ? ValidationStatus::SUCCESS : ValidationStatus::FAILURE;
+    char buf[256];
+    snprintf(buf, sizeof buf,
+             "FFT validation %s (vs float64 DFT: %.3g of peak %.3g; reference golden is %.3g away; "
+             "reference metric vs its golden: %.3g)",
+             ok ? "passed" : "failed", e_out, peak, e_gold, own);
+    v.messages.push_back(buf);
+}
+
+size_t FFTBenchmark::algorithmicBytes() const { return input_fft_bytes + output_fft_bytes; }
+
+// ===========================================================================
+// IIRFilter
+// ===========================================================================
+IIRBenchmark::IIRBenchmark(size_t buffer_size, size_t track_count)
+    : GPUABenchmark("IIRFilter", buffer_size, track_count) {
+    state_count = track_count * STATES_PER_TRACK;
+    state_size_bytes = state_count * sizeof(float);
+}
+
+IIRBenchmark::~IIRBenchmark() {
+    freeHostBuffers({h_coeffs, h_state, cpu_reference, cpu_state_reference});
+    freeDeviceBuffers({d_state});
+}
+
+IIRCoefficients IIRBenchmark::calculateButterworthCoefficients(float normalized_frequency) {
+    // 2nd-order lowpass at fc/fs = normalized_frequency, Q = 0.707 (cuda/bench_iir.cu:199-226)
+    const float PI = 3.14159265358979323846f;
+    float omega = 2.0f * PI * normalized_frequency;
+    float cs = cosf(omega), sn = sinf(omega);
+    float alpha = sn / (2.0f * 0.707f);
+    float b0 = (1.0f - cs) / 2.0f, b1 = 1.0f - cs, b2 = (1.0f - cs) / 2.0f;
+    float a0 = 1.0f + alpha, a1 = -2.0f * cs, a2 = 1.0f - alpha;
+    IIRCoefficients c;
+    c.b0 = b0 / a0; c.b1 = b1 / a0; c.b2 = b2 / a0; c.a1 = a1 / a0; c.a2 = a2 / a0;
+    return c;
+}
+
+void IIRBenchmark::setupBenchmark() {
+    allocateBuffers(getTotalElements());
+    h_coeffs = allocateHostBuffer<IIRCoefficients>(1, benchmark_name_ + " host coefficients buffer");
+    h_state = allocateHostBuffer<float>(state_count, benchmark_name_ + " host state buffer");
+    d_state = allocateDeviceBuffer<float>(state_count, benchmark_name_ + " device state buffer");
+    std::memset(h_state, 0, state_size_bytes);
+    HIP_CHECK(hipMemset(d_state, 0, state_size_bytes));
+    *h_coeffs = calculateButterworthCoefficients(0.25f);
+    say("IIR coefficients: b0=%.6f, b1=%.6f, b2=%.6f, a1=%.6f, a2=%.6f\n", h_coeffs->b0, h_coeffs->b1,
+        h_coeffs->b2, h_coeffs->a1, h_coeffs->a2);
+    generateTestData(42);
+    cpu_reference = allocateHostBuffer<float>(getTotalElements(), "iir cpu reference");
+    cpu_state_reference = allocateHostBuffer<float>(state_count, "iir cpu state reference");
+    std::memset(cpu_state_reference, 0, state_size_bytes);
+    gab::golden::iir(getHostInput(), cpu_reference, h_coeffs, cpu_state_reference,
+                     static_cast<int>(getTrackCount()), static_cast<int>(getBufferSize()));
+    say("IIR filter benchmark setup complete (biquad lowpass filter)\n");
+}
+
+void IIRBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void IIRBenchmark::resetState() {
+    HIP_CHECK(hipMemsetAsync(d_state, 0, state_size_bytes, stream_));
+}
+
+void IIRBenchmark::performBenchmarkIteration() {
+    transferToDevice();
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_iir(getDeviceInput(), getDeviceOutput(), &h_coeffs->b0, d_state,
+                     static_cast<int>(getTrackCount()), static_cast<int>(getBufferSize()), stream_), "gab_iir");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_state, d_state, state_size_bytes, hipMemcpyDeviceToHost, stream_));
+    transferToHost();
+}
+
+void IIRBenchmark::validate(ValidationData& v) {
+    runValidationIteration();                      // zero state -> one buffer: what the golden describes
+    v = compareWithReference(cpu_reference, 1e-4f);
+    float mx = max_abs_diff(h_state, cpu_state_reference, state_count);
+    if (mx > 1e-3f) {
+        v.status = ValidationStatus::FAILURE;
+        v.messages.push_back("IIR state validation failed");
+        v.max_error = std::max(v.max_error, mx);
+    } else if (v.status == ValidationStatus::SUCCESS) {
+        v.messages.push_back("IIR validation passed (output + state)");
+    }
+}
+
+size_t IIRBenchmark::algorithmicBytes() const {
+    return 2 * getTotalElements() * sizeof(float) + 2 * state_size_bytes + sizeof(IIRCoefficients);
+}
+
+// ===========================================================================
+// Conv1D (time domain)
+// ===========================================================================
+Conv1DBenchmark::Conv1DBenchmark(int ir_length, size_t buffer_size, size_t track_count)
+    : GPUABenchmark("Conv1D", buffer_size, track_count), ir_length_(ir_length) {
+    if (ir_length <= 0) throw std::invalid_argument("Conv1DBenchmark: ir_length must be > 0");
+    ir_buffer_size = track_count * ir_length;
+    ir_buffer_bytes = ir_buffer_size * sizeof(float);
+}
+
+Conv1DBenchmark::~Conv1DBenchmark() {
+    freeHostBuffers({h_ir_buf, cpu_reference});
+    freeDeviceBuffers({d_ir_buf});
+}
+
+void Conv1DBenchmark::setupBenchmark() {
+    allocateBuffers(getTotalElements());
+    h_ir_buf = allocateHostBuffer<float>(ir_buffer_size, benchmark_name_ + " host IR buffer");
+    d_ir_buf = allocateDeviceBuffer<float>(ir_buffer_size, benchmark_name_ + " device IR buffer");
+    BenchmarkUtils::generateConv1DImpulseResponses(h_ir_buf, ir_length_, 0, getTrackCount(), getTrackCount());
+    HIP_CHECK(hipMemcpy(d_ir_buf, h_ir_buf, ir_buffer_bytes, hipMemcpyHostToDevice));
+    generateTestData(42);
+    cpu_reference = allocateHostBuffer<float>(getTotalElements(), "conv1d cpu reference");
+    gab::golden::conv1d(getHostInput(), h_ir_buf, cpu_reference, ir_length_,
+                        static_cast<int>(getBufferSize()), static_cast<int>(getTrackCount()));
+    say("Conv1D benchmark setup complete (IR length = %d, taps staged through LDS)\n", ir_length_);
+}
+
+void Conv1DBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void Conv1DBenchmark::performBenchmarkIteration() {
+    transferToDevice();
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_conv1d(getDeviceInput(), getDeviceOutput(), d_ir_buf, ir_length_,
+                        static_cast<int>(getTrackCount()), static_cast<int>(getBufferSize()), stream_),
+             "gab_conv1d");
+    recordGpuDuration(g.finish());
+    transferToHost();
+}
+
+void Conv1DBenchmark::validate(ValidationData& v) {
+    v = compareWithReference(cpu_reference, 1e-3f);        // the reference's (loose) absolute gate
+    const float peak = peak_abs(cpu_reference, getTotalElements());
+    if (peak > 0.0f && v.max_error > 1e-5f * peak) {       // and the 1e-5 relative bar
+        v.status = ValidationStatus::FAILURE;
+        v.messages.push_back("Conv1D peak-normalised error above 1e-5");
+    }
+    if (v.status == ValidationStatus::SUCCESS) v.messages.push_back("Conv1D validation passed");
+}
+
+size_t Conv1DBenchmark::algorithmicBytes() const {
+    return 2 * getTotalElements() * sizeof(float) + ir_buffer_bytes;
+}
+
+// ===========================================================================
+// Conv1D_accel (FFT convolution)
+// ===========================================================================
+Conv1DAccelBenchmark::Conv1DAccelBenchmark(int ir_length, size_t buffer_size, size_t track_count, Mode mode,
+                                           size_t track_offset, size_t total_tracks)
+    : GPUABenchmark("Conv1D_accel", buffer_size, track_count),
+      ir_length_(ir_length),
+      fft_size_(1 << int(ceil(log2(ir_length + buffer_size - 1)))),
+      overlap_size_(ir_length - 1),
+      mode_(mode),
+      track_offset_(track_offset),
+      total_tracks_(total_tracks ? total_tracks : track_count) {
+    if (ir_length <= 0) throw std::invalid_argument("Conv1DAccelBenchmark: ir_length must be > 0");
+    say("Conv1DAccelBenchmark: IR length = %d, FFT size = %d\n", ir_length_, fft_size_);
+    ir_buffer_size = track_count * ir_length;
+    ir_buffer_bytes = ir_buffer_size * sizeof(float);
+}
+
+Conv1DAccelBenchmark::~Conv1DAccelBenchmark() {
+    if (plan_) gab_conv_destroy(plan_);
+    freeHostBuffers({h_ir_buf, cpu_reference});
+    freeDeviceBuffers({d_ir_buf});
+}
+
+void Conv1DAccelBenchmark::setupBenchmark() {
+    say("Setting up Conv1D accelerated benchmark...\n");
+    allocateBuffers(getTotalElements());
+    generateTestData(42);
+    h_ir_buf = allocateHostBuffer<float>(ir_buffer_size, "conv1d_accel host IR buffer");
+    d_ir_buf = allocateDeviceBuffer<float>(ir_buffer_size, "conv1d_accel device IR buffer");
+    cpu_reference = allocateHostBuffer<float>(getTotalElements(), "conv1d_accel cpu reference");
+    checkGab(gab_conv_create(&plan_, static_cast<int>(getTrackCount()), static_cast<int>(getBufferSize()),
+                             ir_length_), "gab_conv_create");
+    BenchmarkUtils::generateConvAccelImpulseResponses(h_ir_buf, ir_length_, track_offset_, getTrackCount(),
+                                                      total_tracks_);
+    HIP_CHECK(hipMemcpyAsync(d_ir_buf, h_ir_buf, ir_buffer_bytes, hipMemcpyHostToDevice, stream_));
+    checkGab(gab_conv_set_ir(plan_, d_ir_buf, stream_), "gab_conv_set_ir");   // spectra bank, once
+    gab::golden::conv_accel(getHostInput(), h_ir_buf, cpu_reference, ir_length_,
+                            static_cast<int>(getBufferSize()), static_cast<int>(getTrackCount()));
+    say("Conv1D accelerated benchmark setup complete.\n");
+}
+
+void Conv1DAccelBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void Conv1DAccelBenchmark::resetState() {
+    checkGab(gab_conv_reset(plan_, stream_), "gab_conv_reset");
+}
+
+void Conv1DAccelBenchmark::performBenchmarkIteration() {
+    if (!plan_) throw std::runtime_error("Convolution plan not initialized");
+    transferToDevice();
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_conv_process(plan_, getDeviceInput(), getDeviceOutput(), static_cast<int>(mode_), stream_),
+             "gab_conv_process");
+    recordGpuDuration(g.finish());
+    transferToHost();
+}
+
+// The golden is the zero-history first buffer, so the validation iteration
+// starts from a reset plan.  Gate: max|gpu-cpu| <= 1e-5 * max|cpu|.  The
+// reference's own metric (max over samples of |err|/|cpu|, tolerance 1e-3) is
+// reported beside it; it is unbounded at the golden's zero crossings.
+void Conv1DAccelBenchmark::validate(ValidationData& v) {
+    runValidationIteration();
+    const size_t n = getTotalElements();
+    const float* gpu = getHostOutput();
+    float max_abs = 0.0f, ref_metric = 0.0f, total_rel = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float e = fabsf(gpu[i] - cpu_reference[i]);
+        float rel = cpu_reference[i] != 0 ? e / fabsf(cpu_reference[i]) : e;
+        max_abs = fmaxf(max_abs, e);
+        ref_metric = fmaxf(ref_metric, rel);
+        total_rel += rel;
+    }
+    const float peak = peak_abs(cpu_reference, n);
+    peak_norm_error_ = peak > 0.0f ? max_abs / peak : max_abs;
+    v.max_error = peak_norm_error_;
+    v.mean_error = total_rel / n;
+    const bool ok = peak_norm_error_ <= 1e-5f;
+    v.status = ok ? ValidationStatus::SUCCESS : ValidationStatus::FAILURE;
+    char buf[256];
+    snprintf(buf, sizeof buf,
+             "Conv1D Accel validation %s (peak-normalised error %.3g, golden peak %.3g; reference metric "
+             "max|err|/|cpu| = %.3g)", ok ? "passed" : "failed", peak_norm_error_, peak, ref_metric);
+    v.messages.push_back(buf);
+}
+
+// streaming: new input + output + every tap + every history sample the taps reach
+// stateless (reference semantics): input + output + the first B taps
+size_t Conv1DAccelBenchmark::algorithmicBytes() const {
+    const size_t T = getTrackCount(), B = getBufferSize(), L = ir_length_;
+    if (mode_ == Mode::STREAMING) return sizeof(float) * T * (2 * B + 2 * L);
+    return sizeof(float) * T * (2 * B + std::min(B, L));
+}
+
+// ===========================================================================
+// ModalFilterBank (placeholder semantics)
+// ===========================================================================
+ModalBenchmark::ModalBenchmark() : GPUABenchmark("Modal", BUFSIZE, MODAL_OUTPUT_TRACKS) {
+    mode_params_size = static_cast<size_t>(NUM_MODES) * NUM_MODE_PARAMS;
+    mode_params_bytes = mode_params_size * sizeof(float);
+    modal_output_size = getBufferSize() * MODAL_OUTPUT_TRACKS;
+    modal_output_bytes = modal_output_size * sizeof(float);
+}
+
+ModalBenchmark::~ModalBenchmark() {
+    freeHostBuffers({h_mode_params, h_modal_output, cpu_reference});
+    freeDeviceBuffers({d_mode_params, d_modal_output});
+}
+
+void ModalBenchmark::setupBenchmark() {
+    h_mode_params = allocateHostBuffer<float>(mode_params_size, benchmark_name_ + " host mode parameters buffer");
+    d_mode_params = allocateDeviceBuffer<float>(mode_params_size, benchmark_name_ + " device mode parameters buffer");
+    h_modal_output = allocateHostBuffer<float>(modal_output_size, benchmark_name_ + " host modal output buffer");
+    d_modal_output = allocateDeviceBuffer<float>(modal_output_size, benchmark_name_ + " device modal output buffer");
+    std::memset(h_modal_output, 0, modal_output_bytes);
+    HIP_CHECK(hipMemset(d_modal_output, 0, modal_output_bytes));
+    srand(42);
+    for (int i = 0; i < NUM_MODES; ++i) {
+        float* p = h_mode_params + static_cast<size_t>(i) * NUM_MODE_PARAMS;
+        for (int k = AMPLITUDE; k <= RESERVED2; ++k) p[k] = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+        p[RESERVED3] = 0.0f;
+    }
+    cpu_reference = allocateHostBuffer<float>(modal_output_size, "modal cpu reference");
+    gab::golden::modal(h_mode_params, cpu_reference, NUM_MODES, static_cast<int>(getBufferSize()), MODAL_OUTPUT_TRACKS);
+    say("Modal benchmark setup complete (%d modes, %d output tracks)\n", NUM_MODES, MODAL_OUTPUT_TRACKS);
+}
+
+void ModalBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void ModalBenchmark::performBenchmarkIteration() {
+    // the reference re-uploads the 32 MiB parameter table every iteration (:72)
+    HIP_CHECK(hipMemcpyAsync(d_mode_params, h_mode_params, mode_params_bytes, hipMemcpyHostToDevice, stream_));
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_modal(d_mode_params, d_modal_output, NUM_MODES, static_cast<int>(getBufferSize()),
+                       MODAL_OUTPUT_TRACKS, stream_), "gab_modal");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_modal_output, d_modal_output, modal_output_bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void ModalBenchmark::validate(ValidationData& v) {
+    v = compareArrays(h_modal_output, cpu_reference, modal_output_size, 1e-5f);
+    v.messages.clear();
+    v.messages.push_back(v.status == ValidationStatus::SUCCESS ? "Modal validation passed"
+                                                               : "Modal validation failed");
+}
+
+size_t ModalBenchmark::algorithmicBytes() const { return mode_params_bytes + modal_output_bytes; }
+
+// ===========================================================================
+// DWG1D
+// ===========================================================================
+const float DWGBenchmark::DEFAULT_REFLECTION_COEFF = 0.99f;
+const float DWGBenchmark::DEFAULT_DAMPING_COEFF = 0.9999f;
+
+DWGBenchmark::DWGBenchmark(Variant variant, size_t buffer_size, size_t track_count)
+    : GPUABenchmark(variant == Variant::NAIVE ? "DWG1DNaive" : "DWG1DAccel", buffer_size, track_count),
+      variant_(variant) {
+    delay_line_size = track_count * DEFAULT_MAX_LENGTH;
+    delay_line_bytes = delay_line_size * sizeof(float);
+    output_buffer_size = buffer_size;
+    output_buffer_bytes = output_buffer_size * sizeof(float);
+}
+
+DWGBenchmark::~DWGBenchmark() {
+    freeHostBuffers({h_waveguide_params, h_dwg_params, h_delay_forward, h_delay_backward, h_input_signal,
+                     h_output_buffer, cpu_reference, cpu_delay_forward, cpu_delay_backward});
+    freeDeviceBuffers({d_waveguide_params, d_delay_forward, d_delay_backward, d_input_signal,
+                       d_output_buffer, d_workspace});
+}
+
+void DWGBenchmark::setupBenchmark() {
+    const size_t T = getTrackCount(), B = getBufferSize();
+    h_waveguide_params = allocateHostBuffer<WaveguideState>(T, benchmark_name_ + " host waveguide params");
+    h_dwg_params = allocateHostBuffer<DWGParams>(1, benchmark_name_ + " host DWG params");
+    h_delay_forward = allocateHostBuffer<float>(delay_line_size, benchmark_name_ + " host delay forward");
+    h_delay_backward = allocateHostBuffer<float>(delay_line_size, benchmark_name_ + " host delay backward");
+    h_input_signal = allocateHostBuffer<float>(B, benchmark_name_ + " host input signal");
+    h_output_buffer = allocateHostBuffer<float>(output_buffer_size, benchmark_name_ + " host output buffer");
+    d_waveguide_params = allocateDeviceBuffer<WaveguideState>(T, benchmark_name_ + " device waveguide params");
+    d_delay_forward = allocateDeviceBuffer<float>(delay_line_size, benchmark_name_ + " device delay forward");
+    d_delay_backward = allocateDeviceBuffer<float>(delay_line_size, benchmark_name_ + " device delay backward");
+    d_input_signal = allocateDeviceBuffer<float>(B, benchmark_name_ + " device input signal");
+    d_output_buffer = allocateDeviceBuffer<float>(output_buffer_size, benchmark_name_ + " device output buffer");
+    d_workspace = allocateDeviceBuffer<char>(gab_dwg_workspace_bytes(static_cast<int>(T), static_cast<int>(B)),
+                                             benchmark_name_ + " device mix workspace");
+    std::memset(h_delay_forward, 0, delay_line_bytes);
+    std::memset(h_delay_backward, 0, delay_line_bytes);
+    std::memset(h_output_buffer, 0, output_buffer_bytes);
+
+    h_dwg_params->numWaveguides = static_cast<int>(T);
+    h_dwg_params->bufferSize = static_cast<int>(B);
+    h_dwg_params->outputTracks = static_cast<int>(T);
+    h_dwg_params->minLength = DEFAULT_MIN_LENGTH;
+    h_dwg_params->maxLength = DEFAULT_MAX_LENGTH;
+    h_dwg_params->reflectionCoeff = DEFAULT_REFLECTION_COEFF;
+    h_dwg_params->dampingCoeff = DEFAULT_DAMPING_COEFF;
+
+    using namespace BenchmarkConstants;
+    srand(42);
+    for (size_t i = 0; i < T; ++i) {
+        WaveguideState& wg = h_waveguide_params[i];
+        wg.length = DEFAULT_MIN_LENGTH + (rand() % (DEFAULT_MAX_LENGTH - DEFAULT_MIN_LENGTH));
+        wg.inputTapPos = wg.length / 4;
+        wg.outputTapPos = 3 * wg.length / 4;
+        wg.writePos = 0;
+        wg.gain = WAVEGUIDE_GAIN_MIN + WAVEGUIDE_GAIN_RANGE * (static_cast<float>(rand()) / static_cast<float>(RAND_MAX));
+        wg.reflection = DEFAULT_REFLECTION_COEFF +
+                        WAVEGUIDE_REFLECTION_PERTURBATION * (static_cast<float>(rand()) / static_cast<float>(RAND_MAX) - 0.5f);
+        wg.damping = DEFAULT_DAMPING_COEFF +
+                     WAVEGUIDE_DAMPING_PERTURBATION * (static_cast<float>(rand()) / static_cast<float>(RAND_MAX) - 0.5f);
+        wg.padding = 0.0f;
+    }
+    for (size_t i = 0; i < B; ++i) h_input_signal[i] = ((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f;
+
+    HIP_CHECK(hipMemcpy(d_waveguide_params, h_waveguide_params, T * sizeof(WaveguideState), hipMemcpyHostToDevice));
+    resetState();
+
+    cpu_reference = allocateHostBuffer<float>(output_buffer_size, "dwg cpu reference");
+    cpu_delay_forward = allocateHostBuffer<float>(delay_line_size, "dwg cpu delay forward");
+    cpu_delay_backward = allocateHostBuffer<float>(delay_line_size, "dwg cpu delay backward");
+    std::memcpy(cpu_delay_forward, h_delay_forward, delay_line_bytes);
+    std::memcpy(cpu_delay_backward, h_delay_backward, delay_line_bytes);
+    gab::golden::dwg(h_waveguide_params, cpu_delay_forward, cpu_delay_backward, h_input_signal, cpu_reference,
+                     h_dwg_params);
+    say("DWG benchmark setup complete (%s variant, %zu waveguides, max length %d)\n",
+        variant_ == Variant::NAIVE ? "Naive" : "Accelerated", T, DEFAULT_MAX_LENGTH);
+}
+
+void DWGBenchmark::resetState() {
+    HIP_CHECK(hipMemsetAsync(d_delay_forward, 0, delay_line_bytes, stream_));
+    HIP_CHECK(hipMemsetAsync(d_delay_backward, 0, delay_line_bytes, stream_));
+}
+
+// Delay lines stay on the device between buffers; only the B-sample input and
+// the B-sample mono mix cross PCIe (the reference moves all state both ways
+// every iteration, cuda/bench_dwg.cu:202-247).
+void DWGBenchmark::runKernel() {
+    const int T = static_cast<int>(getTrackCount()), B = static_cast<int>(getBufferSize());
+    HIP_CHECK(hipMemcpyAsync(d_input_signal, h_input_signal, B * sizeof(float), hipMemcpyHostToDevice, stream_));
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_dwg(reinterpret_cast<const gab_waveguide_state*>(d_waveguide_params), d_delay_forward,
+                     d_delay_backward, d_input_signal, d_output_buffer, d_workspace, T, B, DEFAULT_MAX_LENGTH,
+                     h_dwg_params->outputTracks, variant_ == Variant::NAIVE ? GAB_DWG_NAIVE : GAB_DWG_ACCEL,
+                     stream_), "gab_dwg");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_output_buffer, d_output_buffer, output_buffer_bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DWGBenchmark::performBenchmarkIteration() { runKernel(); }
+
+void DWGBenchmark::validate(ValidationData& v) {
+    runValidationIteration();
+    HIP_CHECK(hipMemcpy(h_delay_forward, d_delay_forward, delay_line_bytes, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(h_delay_backward, d_delay_backward, delay_line_bytes, hipMemcpyDeviceToHost));
+    v = compareArrays(h_output_buffer, cpu_reference, output_buffer_size, 1e-2f);   // reference gate
+    v.messages.clear();
+    delay_max_error_ = std::max(max_abs_diff(h_delay_forward, cpu_delay_forward, delay_line_size),
+                                max_abs_diff(h_delay_backward, cpu_delay_backward, delay_line_size));
+    const float peak = std::max(peak_abs(cpu_delay_forward, delay_line_size), 1e-30f);
+    if (delay_max_error_ > 1e-5f * peak) v.status = ValidationStatus::FAILURE;
+    v.max_error = std::max(v.max_error, delay_max_error_);
+    v.messages.push_back(v.status == ValidationStatus::SUCCESS ? "DWG validation passed (output + delay lines)"
+                                                               : "DWG validation failed");
+}
+
+size_t DWGBenchmark::algorithmicBytes() const {
+    // one forward + one backward cell read and written per sample, plus params, in, out
+    return getTrackCount() * getBufferSize() * 16 + getTrackCount() * sizeof(WaveguideState) +
+           2 * getBufferSize() * sizeof(float);
+}
+
+// ===========================================================================
+// FDTD3D
+// ===========================================================================
+FDTD3DBenchmark::FDTD3DBenchmark(size_t buffer_size, size_t track_count, int grid)
+    : GPUABenchmark("FDTD3D", buffer_size, track_count), grid_(grid) {
+    input_signal_bytes = buffer_size * track_count * sizeof(float);
+    output_buffer_bytes = buffer_size * track_count * sizeof(float);
+}
+
+FDTD3DBenchmark::~FDTD3DBenchmark() {
+    if (plan_) gab_fdtd_destroy(plan_);
+    freeHostBuffers({h_fdtd3d_params, h_input_signal, h_output_buffer, cpu_reference});
+    freeDeviceBuffers({d_input_signal, d_output_buffer});
+}
+
+void FDTD3DBenchmark::setupBenchmark() {
+    const size_t n = getBufferSize() * getTrackCount();
+    gab_fdtd_params gp;
+    checkGab(gab_fdtd_default_params(grid_, grid_, grid_, &gp), "gab_fdtd_default_params");
+    h_fdtd3d_params = allocateHostBuffer<FDTD3DParams>(1, "fdtd3d host params");
+    FDTD3DParams& P = *h_fdtd3d_params;
+    P.nx = gp.nx; P.ny = gp.ny; P.nz = gp.nz;
+    P.sound_speed = kFDTD3D_SoundSpeed;
+    P.spatial_step = kFDTD3D_SpatialStep;
+    P.time_step = kFDTD3D_TimeStep;
+    P.air_density = kFDTD3D_AirDensity;
+    P.absorption_coeff = gp.absorption_coeff;
+    P.source_x = gp.source_x; P.source_y = gp.source_y; P.source_z = gp.source_z;
+    P.receiver_x = gp.receiver_x; P.receiver_y = gp.receiver_y; P.receiver_z = gp.receiver_z;
+    P.buffer_size = static_cast<int>(getBufferSize());
+    P.track_count = static_cast<int>(getTrackCount());
+    P.steps_per_sample = gp.steps_per_sample;
+    P.dt_over_rho_dx = gp.dt_over_rho_dx;
+    P.rho_c2_dt_over_dx = gp.rho_c2_dt_over_dx;
+    checkGab(gab_fdtd_create(&plan_, &gp), "gab_fdtd_create");
+
+    h_input_signal = allocateHostBuffer<float>(n, benchmark_name_ + " host input signal");
+    d_input_signal = allocateDeviceBuffer<float>(n, benchmark_name_ + " device input signal");
+    h_output_buffer = allocateHostBuffer<float>(n, benchmark_name_ + " host output buffer");
+    d_output_buffer = allocateDeviceBuffer<float>(n, benchmark_name_ + " device output buffer");
+    for (size_t i = 0; i < n; ++i) h_input_signal[i] = ((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f;
+    cpu_reference = allocateHostBuffer<float>(n, "fdtd3d cpu reference");
+    gab::golden::fdtd_placeholder(h_input_signal, cpu_reference, getTrackCount(), getBufferSize());
+    say("FDTD3D benchmark setup complete (%dx%dx%d grid, %d steps per sample)\n", P.nx, P.ny, P.nz,
+        P.steps_per_sample);
+}
+
+void FDTD3DBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void FDTD3DBenchmark::resetState() { checkGab(gab_fdtd_reset(plan_, stream_), "gab_fdtd_reset"); }
+
+// All B samples x 3 sub-steps are queued on the stream without a host sync in
+// between (the reference synchronises after every sample, :437).
+void FDTD3DBenchmark::performBenchmarkIteration() {
+    HIP_CHECK(hipMemcpyAsync(d_input_signal, h_input_signal, input_signal_bytes, hipMemcpyHostToDevice, stream_));
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_fdtd_process(plan_, d_input_signal, d_output_buffer, static_cast<int>(getTrackCount()),
+                              static_cast<int>(getBufferSize()), 0, static_cast<int>(getBufferSize()), stream_),
+             "gab_fdtd_process");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_output_buffer, d_output_buffer, output_buffer_bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// The reference golden is a non-physical placeholder compared at 1e-1
+// (:445-459, :271) — kept as a reported number.  The gate here is the real
+// field evolution computed on the host from the same kernels' arithmetic,
+// starting from a reset grid; the host run is bounded to the first
+// `check` samples on large grids (every later sample depends on all earlier
+// ones, so a prefix is still a check of the whole update).
+void FDTD3DBenchmark::validate(ValidationData& v) {
+    const int T = static_cast<int>(getTrackCount()), B = static_cast<int>(getBufferSize());
+    runValidationIteration();
+    ValidationData placeholder = compareArrays(h_output_buffer, cpu_reference, getTotalElements(), 1e-1f);
+
+    gab_fdtd_params gp;
+    checkGab(gab_fdtd_default_params(grid_, grid_, grid_, &gp), "gab_fdtd_default_params");
+    const size_t cells = static_cast<size_t>(gp.nx) * gp.ny * gp.nz;
+    const int check = cells <= 200000 ? B : std::min(B, 32);
+    std::vector<float> p(cells, 0.0f), vx((size_t)(gp.nx + 1) * gp.ny * gp.nz, 0.0f),
+        vy((size_t)gp.nx * (gp.ny + 1) * gp.nz, 0.0f), vz((size_t)gp.nx * gp.ny * (gp.nz + 1), 0.0f);
+    std::vector<float> ref(getTotalElements(), 0.0f);
+    gab::golden::fdtd3d(gp, p.data(), vx.data(), vy.data(), vz.data(), h_input_signal, ref.data(), T, B, 0, check);
+    float mx = 0.0f, peak = 0.0f;
+    for (int t = 0; t < T; ++t)
+        for (int s = 0; s < check; ++s) {
+            size_t i = static_cast<size_t>(t) * B + s;
+            mx = std::max(mx, std::abs(h_output_buffer[i] - ref[i]));
+            peak = std::max(peak, std::abs(ref[i]));
+        }
+    field_max_error_ = mx;
+    v = ValidationData{};
+    v.max_error = mx;
+    v.mean_error = placeholder.mean_error;
+    const bool ok = mx <= 1e-5f * std::max(peak, 1e-30f);
+    v.status = ok ? ValidationStatus::SUCCESS : ValidationStatus::FAILURE;
+    char buf[256];
+    snprintf(buf, sizeof buf,
+             "FDTD3D validation %s (field error %.3g over %d samples, receiver peak %.3g; distance to the "
+             "reference's placeholder golden %.3g)", ok ? "passed" : "failed", mx, check, peak,
+             placeholder.max_error);
+    v.messages.push_back(buf);
+}
+
+size_t FDTD3DBenchmark::algorithmicBytes() const {
+    const size_t n = grid_;
+    const size_t per_step = 2 * sizeof(float) * (n * n * n + 3 * (n + 1) * n * n);
+    return per_step * kFDTD3D_StepsPerSample * getBufferSize();
+}
+
+// ===========================================================================
+// RndMemRead
+// ===========================================================================
+RndMemBenchmark::RndMemBenchmark(size_t buffer_size, size_t track_count, int min_loop_len, int max_loop_len)
+    : GPUABenchmark("RndMem", buffer_size, track_count),
+      min_loop_length_(min_loop_len), max_loop_length_(max_loop_len) {
+    sample_memory_bytes = static_cast<size_t>(SAMPLE_MEM_NUM_ELEMS) * sizeof(float);
+    playheads_bytes = track_count * sizeof(int);
+    output_buffer_bytes = track_count * buffer_size * sizeof(float);
+    sample_buffer_end_ = SAMPLE_MEM_NUM_ELEMS - static_cast<int>(buffer_size);
+}
+
+RndMemBenchmark::~RndMemBenchmark() {
+    freeHostBuffers({h_sample_memory, h_playheads, h_output_buffer, playheads_start, playheads_end, cpu_reference});
+    freeDeviceBuffers({d_sample_memory, d_playheads, d_output_buffer});
+}
+
+void RndMemBenchmark::setupBenchmark() {
+    const size_t T = getTrackCount(), B = getBufferSize();
+    h_sample_memory = allocateHostBuffer<float>(SAMPLE_MEM_NUM_ELEMS, benchmark_name_ + " host sample memory");
+    d_sample_memory = allocateDeviceBuffer<float>(SAMPLE_MEM_NUM_ELEMS, benchmark_name_ + " device sample memory");
+    h_playheads = allocateHostBuffer<int>(T, benchmark_name_ + " host playheads");
+    d_playheads = allocateDeviceBuffer<int>(T, benchmark_name_ + " device playheads");
+    h_output_buffer = allocateHostBuffer<float>(B * T, benchmark_name_ + " host output buffer");
+    d_output_buffer = allocateDeviceBuffer<float>(B * T, benchmark_name_ + " device output buffer");
+    playheads_start = allocateHostBuffer<float>(T, "rndmem playheads start");
+    playheads_end = allocateHostBuffer<float>(T, "rndmem playheads end");
+    std::memset(h_output_buffer, 0, output_buffer_bytes);
+
+    srand(42);
+    for (int i = 0; i < SAMPLE_MEM_NUM_ELEMS; ++i)
+        h_sample_memory[i] = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+    say("Transferring 512MB sample memory to device...\n");
+    HIP_CHECK(hipMemcpy(d_sample_memory, h_sample_memory, sample_memory_bytes, hipMemcpyHostToDevice));
+    say("Sample memory transfer complete.\n");
+
+    initializePlayheads();
+    cpu_reference = allocateHostBuffer<float>(T * B, "rndmem cpu reference");
+    gab::golden::rndmem(h_sample_memory, h_playheads, cpu_reference, static_cast<int>(B), static_cast<int>(T));
+    say("RndMem benchmark setup complete (512MB sample memory, %zu tracks, random access)\n", T);
+}
+
+void RndMemBenchmark::initializePlayheads() {
+    srand(42);
+    for (size_t i = 0; i < getTrackCount(); ++i) {
+        // start/end are kept as floats, as in the reference (24-bit mantissa rounding included)
+        playheads_start[i] = static_cast<float>(rand() % sample_buffer_end_);
+        int loop_len = min_loop_length_ + (rand() % (max_loop_length_ - min_loop_length_));
+        playheads_end[i] = playheads_start[i] + loop_len;
+        if (playheads_end[i] >= sample_buffer_end_) playheads_end[i] = sample_buffer_end_ - 1;
+        h_playheads[i] = static_cast<int>(playheads_start[i]);
+    }
+    say("Initialized %zu tracks with random loop lengths (%d-%d samples)\n", getTrackCount(),
+        min_loop_length_, max_loop_length_);
+}
+
+void RndMemBenchmark::updatePlayheads() {
+    for (size_t i = 0; i < getTrackCount(); ++i) {
+        h_playheads[i] += static_cast<int>(getBufferSize());
+        if (h_playheads[i] >= static_cast<int>(playheads_end[i]))
+            h_playheads[i] = static_cast<int>(playheads_start[i]);
+    }
+}
+
+void RndMemBenchmark::resetState() {
+    for (size_t i = 0; i < getTrackCount(); ++i) h_playheads[i] = static_cast<int>(playheads_start[i]);
+}
+
+void RndMemBenchmark::runKernel() { performBenchmarkIteration(); }
+
+void RndMemBenchmark::performBenchmarkIteration() {
+    HIP_CHECK(hipMemcpyAsync(d_playheads, h_playheads, playheads_bytes, hipMemcpyHostToDevice, stream_));
+    ScopedGpuTimer g(stream_);
+    checkGab(gab_rndmem(d_sample_memory, d_playheads, d_output_buffer, static_cast<int>(getTrackCount()),
+                        static_cast<int>(getBufferSize()), stream_), "gab_rndmem");
+    recordGpuDuration(g.finish());
+    HIP_CHECK(hipMemcpyAsync(h_output_buffer, d_output_buffer, output_buffer_bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    updatePlayheads();
+}
+
+void RndMemBenchmark::validate(ValidationData& v) {
+    runValidationIteration();                 // the golden was taken at the initial playheads
+    v = compareArrays(h_output_buffer, cpu_reference, getBufferSize() * getTrackCount(), 0.0f);
+    v.messages.clear();
+    v.messages.push_back(v.status == ValidationStatus::SUCCESS
+                             ? "RndMem validation passed (memory access patterns verified)"
+                             : "RndMem validation failed");
+}
+
+// ===========================================================================
+// Registry
+// ===========================================================================
+namespace gab {
+
+namespace {
+struct Entry {
+    const char* name;
+    std::unique_ptr<GPUABenchmark> (*make)();
+};
+
+template <class T, class... A>
+std::unique_ptr<GPUABenchmark> mk(A... a) { return std::unique_ptr<GPUABenchmark>(new T(a...)); }
+
+const Entry kRegistry[] = {
+    {"NoOp", [] { return mk<NoOpBenchmark>(); }},
+    {"gain", [] { return mk<GainBenchmark>(); }},
+    {"GainStats", [] { return mk<GainStatsBenchmark>(); }},
+    {"datacopy0199", [] { return mk<DataTransferBenchmark>(0.01f, 0.99f); }},
+    {"datacopy2080", [] { return mk<DataTransferBenchmark>(0.20f, 0.80f); }},
+    {"datacopy5050", [] { return mk<DataTransferBenchmark>(0.50f, 0.50f); }},
+    {"datacopy8020", [] { return mk<DataTransferBenchmark>(0.80f, 0.20f); }},
+    {"datacopy9901", [] { return mk<DataTransferBenchmark>(0.99f, 0.01f); }},
+    {"FFT1D", [] { return mk<FFTBenchmark>(); }},
+    {"IIRFilter", [] { return mk<IIRBenchmark>(); }},
+    {"Conv1D", [] { return mk<Conv1DBenchmark>(); }},
+    {"Conv1D_accel", [] { return mk<Conv1DAccelBenchmark>(); }},
+    {"ModalFilterBank", [] { return mk<ModalBenchmark>(); }},
+    {"DWG1DNaive", [] { return mk<DWGBenchmark>(DWGBenchmark::Variant::NAIVE); }},
+    {"DWG1DAccel", [] { return mk<DWGBenchmark>(DWGBenchmark::Variant::ACCELERATED); }},
+    {"FDTD3D", [] { return mk<FDTD3DBenchmark>(); }},
+    {"RndMemRead", [] { return mk<RndMemBenchmark>(); }},
+};
+}  // namespace
+
+const std::vector<std::string>& benchmarkNames() {
+    static const std::vector<std::string> names = [] {
+        std::vector<std::string> v;
+        for (const Entry& e : kRegistry) v.emplace_back(e.name);
+        return v;
+    }();
+    return names;
+}
+
+std::unique_ptr<GPUABenchmark> createBenchmark(const std::string& name) {
+    for (const Entry& e : kRegistry)
+        if (name == e.name) return e.make();
+    return nullptr;
+}
+
+}  // namespace gab

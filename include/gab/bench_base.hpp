@@ -1,0 +1,133 @@
+// bench_base.hpp — GPUABenchmark, the plugin interface of the benchmark suite.
+//
+// This is the drop-in boundary: the class keeps the public and protected
+// surface of the reference's cuda/bench_base.cuh:18-139 (same type, method and
+// member names, same defaults, same exception behaviour), so a main.cu-style
+// driver and benchmark subclasses written against the reference compile against
+// it.  Differences are additive:
+//   * every benchmark owns a HIP stream; host<->device copies are
+//     hipMemcpyAsync on pinned memory (the reference uses synchronous
+//     cudaMemcpy on the default stream);
+//   * resetState() + runValidationIteration(): state-carrying benchmarks (IIR,
+//     DWG, FDTD3D, RndMem, streaming convolution) are validated on "reset ->
+//     one iteration -> compare", which is the iteration their CPU golden
+//     describes (the reference compares its LAST timed
+//     iteration against a golden of the FIRST);
+//   * algorithmicBytes(): the roofline numerator for the benchmark's kernel.
+#pragma once
+
+#include <cstdio>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "bench_utils.hpp"
+#include "globals.hpp"
+
+class GPUABenchmark {
+public:
+    struct BenchmarkResult {
+        std::vector<float> latencies;          // wall ms per iteration (copies included)
+        std::vector<float> gpu_latencies;      // device ms per iteration, when recorded
+        BenchmarkUtils::Statistics statistics;
+        BenchmarkUtils::Statistics gpu_statistics;
+        std::string benchmark_name;
+        size_t buffer_size;
+        size_t track_count;
+        int iterations;
+        double throughput_gbps;                // bytes_processed / mean latency, GiB/s
+        double samples_per_sec;
+        size_t bytes_processed;
+        float mean_latency_ms;
+    };
+
+    enum class ValidationStatus { SUCCESS = 0, FAILURE = 1, FATAL = -1 };
+
+    struct ValidationData {
+        ValidationStatus status = ValidationStatus::SUCCESS;
+        std::vector<std::string> messages;
+        float max_error = 0.0f;
+        float mean_error = 0.0f;
+    };
+
+protected:
+    // Two pinned host buffers and two device buffers of element_count floats.
+    struct BufferSet {
+        float* h_input = nullptr;
+        float* h_output = nullptr;
+        float* d_input = nullptr;
+        float* d_output = nullptr;
+        size_t element_count = 0;
+        size_t size_bytes = 0;
+
+        ~BufferSet() { cleanup(); }
+        void cleanup();
+    };
+
+    BufferSet buffers;
+    BenchmarkUtils::BenchmarkTimer timer;
+    std::string benchmark_name_;
+    size_t buffer_size_;
+    size_t track_count_;
+    float current_iteration_gpu_ms_ = 0.0f;
+    hipStream_t stream_ = nullptr;             // all of this benchmark's device work
+
+public:
+    GPUABenchmark(const std::string& name, size_t buffer_size = BUFSIZE, size_t track_count = NTRACKS);
+    virtual ~GPUABenchmark();
+    GPUABenchmark(const GPUABenchmark&) = delete;
+    GPUABenchmark& operator=(const GPUABenchmark&) = delete;
+
+    // ---- what a benchmark implements (bench_base.cuh:94-97) -----------------
+    virtual void setupBenchmark() = 0;
+    virtual void runKernel() = 0;
+    virtual void performBenchmarkIteration() = 0;
+    virtual void validate(ValidationData& validation_data) = 0;
+
+    // ---- additive hooks --------------------------------------------------------
+    virtual void resetState() {}
+    virtual void runValidationIteration() { resetState(); performBenchmarkIteration(); }
+    virtual size_t algorithmicBytes() const { return 2 * getTotalElements() * sizeof(float); }
+
+    // ---- provided (bench_base.cuh:103-110) -----------------------------------------
+    void allocateBuffers(size_t element_count);
+    void transferToDevice();
+    void transferToHost();
+    BenchmarkResult runKernelBenchmark(int iterations = NRUNS, int warmupIterations = 3);
+    BenchmarkResult runBenchmark(int iterations = NRUNS, int warmupIterations = 3);
+    void generateTestData(unsigned int seed = 42);
+    void writeResults(const BenchmarkResult& result, const std::string& filename = "");
+    void printResults(const BenchmarkResult& result);
+
+    const std::string& getName() const { return benchmark_name_; }
+    size_t getBufferSize() const { return buffer_size_; }
+    size_t getTrackCount() const { return track_count_; }
+    size_t getTotalElements() const { return buffer_size_ * track_count_; }
+    hipStream_t getStream() const { return stream_; }
+
+    // read-only views for tests and bindings
+    const float* hostInput() const { return buffers.h_input; }
+    const float* hostOutput() const { return buffers.h_output; }
+
+protected:
+    float* getHostInput() { return buffers.h_input; }
+    float* getHostOutput() { return buffers.h_output; }
+    float* getDeviceInput() { return buffers.d_input; }
+    float* getDeviceOutput() { return buffers.d_output; }
+    BenchmarkUtils::BenchmarkParams makeBenchmarkParams(float gainValue = 0.0f) const;
+    std::pair<int, int> calculateGridDimensions(int desired_threads_per_block = 256) const;
+    void synchronizeAndCheck();
+    ValidationData compareWithReference(const float* cpu_reference, float tolerance = 1e-5f);
+    void resetGpuIterationMetrics();
+    void recordGpuDuration(float milliseconds);
+    BenchmarkResult runWithIteration(int iterations, int warmupIterations,
+                                     const std::function<void()>& iterationBody);
+
+    // compare any pair of host arrays with the same bookkeeping as compareWithReference
+    static ValidationData compareArrays(const float* got, const float* expected, size_t n, float tolerance);
+    // throws std::runtime_error carrying gab_last_error() when a C-ABI call fails
+    static void checkGab(int rc, const char* what);
+};

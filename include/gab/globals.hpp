@@ -1,0 +1,34 @@
+// globals.hpp — CLI-backed process globals and the legacy result writers
+// (reference: cuda/globals.cuh:20-42, cuda/globals.cu).  Names and defaults are
+// the reference's; the CSV / JSON formats are byte-compatible with it.
+#pragma once
+
+#include <string>
+#include <vector>
+
+extern int NTRACKS;              // --nTracks      (128)
+extern int FS;                   // --fs           (48000)
+extern int BUFSIZE;              // --bufferSize   (512)
+extern int NRUNS;                // --nRuns        (100)
+extern std::string OUTPUT_FILE;  // --outputfile   ("")
+extern bool JSON_OUTPUT;         // --json
+
+// Additions of the MI355X build (unreachable from the reference CLI):
+extern int IR_LENGTH;            // --irLength     (<=0: each benchmark's DEFAULT_IR_LEN)
+extern int FDTD_GRID;            // --fdtdGrid     (<=0: 52, the reference's 50+2)
+extern int CONV_STREAMING;       // --convMode stream|stateless (default stream)
+extern bool GAB_QUIET;           // suppress progress chatter (library use)
+
+// DAW-simulation knobs exist in the reference as compile-time macros, all off
+// (cuda/globals.cuh:28-30).
+#define ENABLE_DAWSIM_SLEEP false
+#define SLEEP_MS 90
+#define ENABLE_DAWSIM_SPIN false
+
+void writeVectorToFile(const std::vector<float>& vec, const std::string& filename);
+void printVectorStats(const std::vector<float>& vec);
+void writeCSVResults(const std::vector<float>& vec, const std::string& benchmarkName,
+                     const std::string& filename);
+void writeJSONResults(const std::vector<float>& vec, const std::string& benchmarkName,
+                      const std::string& filename = "");
+std::string generateJSONResults(const std::vector<float>& vec, const std::string& benchmarkName);

@@ -166,6 +166,38 @@ int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
 int gab_fdtd_copy_pressure(gab_fdtd_plan* plan, float* d_dst, gab_stream_t stream);
 
 /* ===================================================================== */
+/* G. host-side data generators of the harness                           */
+/* ===================================================================== */
+
+/* generateRandomAudioData (cuda/bench_utils.cu:238-245): mt19937(seed), U(-1,1). */
+int gab_generate_noise(float* h_buf, size_t n, unsigned seed);
+/* Conv1DBenchmark::generateImpulseResponses (cuda/bench_conv1d.cu:159-181) and
+ * Conv1DAccelBenchmark::generateImpulseResponses (cuda/bench_conv1d_accel.cu:
+ * 152-173).  The formulas use the GLOBAL track index and count: a shard asks
+ * for tracks [track_offset, track_offset+n_tracks) of a bank of total_tracks.  */
+int gab_generate_conv1d_ir(float* h_ir, int ir_len, size_t track_offset,
+                           size_t n_tracks, size_t total_tracks);
+int gab_generate_conv_accel_ir(float* h_ir, int ir_len, size_t track_offset,
+                               size_t n_tracks, size_t total_tracks);
+
+/* calculateStatistics (cuda/bench_utils.cu:358-414): mean, median, sample
+ * std-dev, min, max, linearly interpolated p95/p99.                          */
+typedef struct {
+    float  mean, median, std_dev, min_val, max_val, p95, p99;
+    size_t count;
+} gab_statistics;
+int gab_calculate_statistics(const float* latencies, size_t n, gab_statistics* out);
+/* The CLI-backed process globals the legacy writers read (cuda/globals.cu:4-7). */
+int gab_set_globals(int fs, int buffer_size, int n_tracks, int n_runs);
+/* generateJSONResults (cuda/globals.cu:137-182) into buf (NUL-terminated);
+ * returns the length the full text needs, excluding the NUL.                 */
+size_t gab_format_json_results(const float* latencies, size_t n, const char* name,
+                               char* buf, size_t capacity);
+/* writeCSVResults (cuda/globals.cu:69-122): appends one row, header if new.  */
+int gab_write_csv_results(const float* latencies, size_t n, const char* name,
+                          const char* filename);
+
+/* ===================================================================== */
 /* H. harness (GPUABenchmark by registry name)                           */
 /* ===================================================================== */
 
@@ -200,6 +232,10 @@ int  gab_bench_destroy(gab_bench* b);
 int  gab_bench_setup(gab_bench* b);
 int  gab_bench_run(gab_bench* b, int iterations, int warmup, gab_bench_result* out);
 int  gab_bench_validate(gab_bench* b, gab_bench_validation* out);
+/* text of the validation messages of the last gab_bench_validate, '\n'-joined */
+const char* gab_bench_validation_text(gab_bench* b);
+/* roofline numerator of one iteration (GPUABenchmark::algorithmicBytes)      */
+int  gab_bench_algorithmic_bytes(gab_bench* b, size_t* bytes);
 /* latencies of the last run (ms); returns how many were copied               */
 int  gab_bench_latencies(gab_bench* b, float* out, int capacity);
 

@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/gab_c_api.h declares
+(no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gab_c_api.h")
+LIB = os.path.join(ROOT, "gpuaudiobench_amd", "libgab_hip.so")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(gab_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("gab_gain", "gab_conv_process", "gab_fdtd_process", "gab_bench_create",
+                 "gab_fft_r2c_1024", "gab_rndmem", "gab_dwg", "gab_iir", "gab_modal",
+                 "gab_datatransfer", "gab_gainstats", "gab_noop", "gab_conv1d"):
+        assert must in names
+    assert len(names) >= 40
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "build it with: python gpuaudiobench_amd/build.py"
+    lib = ctypes.CDLL(LIB)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_table_matches_header():
+    from gpuaudiobench_amd import _capi
+    assert sorted(_capi.PROTOTYPES) == declared_functions()
+
+
+def test_version_and_errors_without_gpu():
+    from gpuaudiobench_amd import _capi
+    assert _capi.lib.gab_version() == 100
+    # argument validation happens before any device call
+    assert _capi.lib.gab_gainstats(None, None, None, 0, 0, 0.5, None) == _capi.GAB_ERR_INVALID_ARG
+    assert b"null pointer" in _capi.lib.gab_last_error()
+    h = ctypes.c_void_p()
+    assert _capi.lib.gab_conv_create(ctypes.byref(h), -1, 512, 512) == _capi.GAB_ERR_INVALID_ARG
+    assert _capi.lib.gab_bench_create(ctypes.byref(h), b"NoSuchBenchmark", None) == _capi.GAB_ERR_INVALID_ARG
+
+
+def test_product_package_does_not_touch_the_oracle():
+    """The product may not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "gpuaudiobench_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "gab_oracle" not in text and "orc_" not in text, f
+    out = os.popen("ldd %s" % LIB).read()
+    assert "oracle" not in out

@@ -1,0 +1,100 @@
+"""The harness end to end on the GPU: every registry name sets up, runs and
+validates against its CPU golden; the gpubench driver speaks the reference CLI."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "gpuaudiobench_amd", "gpubench")
+
+NAMES = ["NoOp", "gain", "GainStats", "datacopy0199", "datacopy2080", "datacopy5050",
+         "datacopy8020", "datacopy9901", "FFT1D", "IIRFilter", "Conv1D", "Conv1D_accel",
+         "ModalFilterBank", "DWG1DNaive", "DWG1DAccel", "FDTD3D", "RndMemRead"]
+
+
+@pytest.fixture(scope="module")
+def gab():
+    import torch
+    assert torch.cuda.is_available()
+    import gpuaudiobench_amd as g
+    return g
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_every_registered_benchmark_validates(gab, name):
+    cfg = dict(n_tracks=128, buffer_size=512)
+    if name == "FDTD3D":
+        cfg.update(n_tracks=16, buffer_size=64)       # 52^3 x 192 steps; host check of every sample
+    b = gab.Benchmark(name, **cfg)
+    b.setup()
+    r = b.run(iterations=4, warmup=2)
+    assert r.iterations == 4 and r.mean_ms > 0 and r.min_ms <= r.median_ms <= r.max_ms
+    v, text = b.validate()
+    assert v.status == 0, (name, text, v.max_error)
+    assert b.algorithmic_bytes() > 0
+    lat = b.latencies()
+    assert lat.size == 4 and np.all(lat > 0)
+    b.close()
+
+
+@pytest.mark.parametrize("mode", ["stream", "stateless"])
+def test_conv_accel_c3_through_the_harness(gab, mode):
+    b = gab.Benchmark("Conv1D_accel", n_tracks=1024, buffer_size=512, ir_length=4096,
+                      conv_mode=gab.CONV_STREAMING if mode == "stream" else gab.CONV_STATELESS)
+    b.setup()
+    r = b.run(iterations=20, warmup=3)
+    v, text = b.validate()
+    assert v.status == 0 and v.max_error <= 1e-5, text
+    T, B, L = 1024, 512, 4096
+    expect = 4 * T * (2 * B + 2 * L) if mode == "stream" else 4 * T * 3 * B
+    assert b.algorithmic_bytes() == expect                   # 37 748 736 / 6 291 456
+    assert r.gpu_median_ms > 0
+    b.close()
+
+
+def test_fdtd_128_grid_prefix_validates(gab):
+    b = gab.Benchmark("FDTD3D", n_tracks=8, buffer_size=16, fdtd_grid=128)
+    b.setup()
+    b.run(iterations=1, warmup=0)
+    v, text = b.validate()
+    assert v.status == 0, text
+    assert v.max_error == 0.0, text                          # same arithmetic on both sides
+    b.close()
+
+
+def run_driver(*args):
+    return subprocess.run([DRIVER, *args], capture_output=True, text=True, timeout=600)
+
+
+def test_driver_list_and_help():
+    r = run_driver("--list")
+    assert r.returncode == 0
+    assert r.stdout.split("\n")[2:19] == NAMES
+    assert "Usage: gpubench [options]" in run_driver("--help").stdout
+
+
+def test_driver_runs_gain_and_writes_reference_outputs(tmp_path):
+    csv = str(tmp_path / "r.csv")
+    r = run_driver("--benchmark", "gain", "--nRuns", "7", "--nTracks", "64", "--outputfile", csv)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Validation passed for gain" in r.stdout and "gain benchmark completed successfully!" in r.stdout
+    assert "=== Gain Benchmark Results ===" in r.stdout           # benchmark_name_, not the registry key
+    assert os.path.exists("/tmp/Gain_latencies.txt")              # cuda/bench_base.cu:120-127
+    rows = open(csv).read().splitlines()
+    assert rows[0].startswith("benchmark,fs,bufferSize,nTracks,nRuns,") and rows[1].startswith("gain,48000,512,64,7,")
+
+
+def test_driver_json_and_unknown_name():
+    r = run_driver("--benchmark", "IIRFilter", "--nRuns", "5", "--json")
+    assert r.returncode == 0
+    start = r.stdout.index('{\n  "benchmark"')
+    d = json.loads(r.stdout[start:r.stdout.index("\n}\n", start) + 3])
+    assert d["benchmark"] == "IIRFilter" and d["configuration"]["nRuns"] == 5
+    r = run_driver("--benchmark", "nope")
+    assert r.returncode == 1 and "Unknown benchmark 'nope'" in r.stdout
+    assert run_driver("--benchmark").returncode == 1

@@ -1,0 +1,90 @@
+"""Host-side logic of the harness against the oracle: generators, statistics,
+legacy writers, registry.  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gpuaudiobench_amd as gab
+from gpuaudiobench_amd import harness as H
+
+
+def test_registry_names_and_order():
+    # cuda/main.cu:84-100
+    assert H.benchmark_names() == [
+        "NoOp", "gain", "GainStats", "datacopy0199", "datacopy2080", "datacopy5050",
+        "datacopy8020", "datacopy9901", "FFT1D", "IIRFilter", "Conv1D", "Conv1D_accel",
+        "ModalFilterBank", "DWG1DNaive", "DWG1DAccel", "FDTD3D", "RndMemRead"]
+
+
+@pytest.mark.parametrize("n,seed", [(1, 42), (65536, 42), (1000, 7)])
+def test_noise_generator_matches_oracle(orc, n, seed):
+    assert np.array_equal(H.noise(n, seed), orc.noise(n, seed))
+
+
+def test_noise_pin():
+    x = H.noise(65536)
+    assert float("%.9g" % x[0]) == -0.250919759 and float("%.9g" % x[65535]) == -0.69250834
+
+
+@pytest.mark.parametrize("L,T,off,total", [(256, 256, 0, 256), (4096, 16, 1000, 8192), (512, 3, 0, 3)])
+def test_ir_generators_match_oracle(orc, L, T, off, total):
+    assert np.array_equal(H.conv_accel_ir(L, T, off, total), orc.conv_accel_ir(L, T, off, total))
+    if off == 0:
+        assert np.array_equal(H.conv1d_ir(L, T), orc.conv1d_ir(L, T))
+
+
+def test_sharded_ir_equals_slice_of_global_bank():
+    full = H.conv_accel_ir(512, 64).reshape(64, 512)
+    for r in range(4):
+        part = H.conv_accel_ir(512, 16, track_offset=16 * r, total_tracks=64).reshape(16, 512)
+        assert np.array_equal(part, full[16 * r:16 * r + 16])
+
+
+@pytest.mark.parametrize("lat", [[1, 2, 3, 4, 10], [5.0], [0.25, 0.5, 0.125, 7, 3, 3, 3, 9.5],
+                                 list(np.linspace(0.1, 11, 100))])
+def test_statistics_match_oracle(orc, lat):
+    a, b = H.statistics(lat), orc.statistics(np.array(lat, np.float32))
+    for f in ("mean", "median", "min_val", "max_val", "p95", "p99", "count"):
+        assert getattr(a, f) == getattr(b, f), f
+    if len(lat) > 1:
+        assert a.std_dev == b.std_dev
+
+
+def test_json_results_format():
+    H.set_globals(fs=48000, buffer_size=512, n_tracks=128, n_runs=100)
+    lat = [1.0, 2.0, 3.0, 12.0]
+    txt = H.json_results(lat, "Conv1D_accel")
+    d = json.loads(txt)
+    assert d["benchmark"] == "Conv1D_accel"
+    assert d["configuration"] == {"fs": 48000, "bufferSize": 512, "nTracks": 128, "nRuns": 4}
+    # nearest-rank percentiles of the legacy writer: index = int(n*p)  (cuda/globals.cu:86-88)
+    assert d["statistics"]["p50_ms"] == 3.0 and d["statistics"]["p99_ms"] == 12.0
+    assert abs(d["deadline"]["threshold_ms"] - 1000.0 * 512 / 48000) < 1e-5
+    assert d["deadline"]["meets_deadline"] is False
+    assert txt.startswith('{\n  "benchmark": "Conv1D_accel",\n  "configuration": {\n    "fs": 48000,')
+
+
+def test_csv_results_format(tmp_path):
+    H.set_globals(fs=44100, buffer_size=256, n_tracks=64, n_runs=3)
+    f = str(tmp_path / "out.csv")
+    H.write_csv_results([0.5, 0.25, 1.0], "gain", f)
+    H.write_csv_results([0.5, 0.25, 9.0], "gain", f)
+    lines = open(f).read().splitlines()
+    assert lines[0] == ("benchmark,fs,bufferSize,nTracks,nRuns,min_ms,max_ms,avg_ms,p50_ms,p95_ms,"
+                        "p99_ms,threshold_ms,meets_deadline")
+    assert len(lines) == 3                                # header written once
+    cols = lines[1].split(",")
+    assert cols[:5] == ["gain", "44100", "256", "64", "3"]
+    assert cols[-1] == "true" and lines[2].split(",")[-1] == "false"
+    H.set_globals()
+
+
+def test_bench_config_validation():
+    with pytest.raises(gab.GabError):
+        gab.Benchmark("gain", n_tracks=0)
+    with pytest.raises(gab.GabError):
+        gab.Benchmark("not-a-benchmark")
+    with pytest.raises(TypeError):
+        gab.Benchmark("gain", bogus=1)
