@@ -169,9 +169,47 @@ struct Pad {
     __host__ __device__ static constexpr int size(int n) { return n + (n >> SH); }
 };
 
+__device__ __forceinline__ cf csqr(cf a) {
+    return mk(__builtin_fmaf(a.x, a.x, -(a.y * a.y)), 2.0f * (a.x * a.y));
+}
+
+// Twiddles of one transform shape: for every pass p >= 1 the R-1 factors
+// W_{Ns*R}^(r*k), r = 1..R-1, k = tid mod Ns.  They depend on tid only, so a
+// kernel forms them once — one table read per pass (w^1) plus in-register
+// powers (products at most four deep, ~3e-7 relative) — ideally while it waits
+// for its first data, and reuses them for the forward AND the inverse transform
+// (the inverse conjugates).  A per-lane gather of all R-1 powers from a table
+// costs R-1 scattered L1 transactions per pass and was this kernel's first
+// bottleneck.
+template <int R, int PASSES>
+struct TwiddleSet {
+    cf w[PASSES > 1 ? PASSES - 1 : 1][R - 1];
+};
+
+template <int R>
+__device__ __forceinline__ void powers_of(cf w, cf (&out)[R - 1]) {
+    out[0] = w;
+    if constexpr (R >= 4) {
+        out[1] = csqr(w);
+        out[2] = cmul(out[1], w);
+    }
+    if constexpr (R >= 8) {
+        out[3] = csqr(out[1]);
+        out[4] = cmul(out[3], w);
+        out[5] = cmul(out[3], out[1]);
+        out[6] = cmul(out[3], out[2]);
+    }
+    if constexpr (R >= 16) {
+        out[7] = csqr(out[3]);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) out[8 + i] = cmul(out[7], out[i]);
+    }
+}
+
 // One workgroup-wide transform.  `ldsA`/`ldsB` each hold Pad<R>::size(N) cf.
-// All NT threads must call it (it contains barriers).  On return the two
-// buffers may be reused after the caller's next barrier.
+// All NT threads must call it (it contains barriers).  On return the last pass
+// has read from `ldsB`; a caller chains stages so that each stage first writes
+// the buffer whose last readers are already behind a barrier.
 template <int N, int R, bool INV>
 struct BlockFFT {
     static constexpr int NT = N / R;
@@ -179,10 +217,21 @@ struct BlockFFT {
     static_assert(ipow(R, PASSES) == N, "N must be a power of R");
     static_assert(kTwiddleN % N == 0, "twiddle table too small");
     using P = Pad<R>;
+    using Twiddles = TwiddleSet<R, PASSES>;
+
+    __device__ static __forceinline__ void load_twiddles(Twiddles& t, const cf* __restrict__ tw, int tid) {
+        cf base[PASSES];
+#pragma unroll
+        for (int p = 1; p < PASSES; ++p) {
+            const int Ns = ipow(R, p);
+            base[p] = tw[(tid & (Ns - 1)) * (kTwiddleN / (Ns * R))];
+        }
+#pragma unroll
+        for (int p = 1; p < PASSES; ++p) powers_of<R>(base[p], t.w[p - 1]);
+    }
 
     __device__ static __forceinline__ void run(cf (&v)[R], cf* __restrict__ ldsA,
-                                               cf* __restrict__ ldsB,
-                                               const cf* __restrict__ tw, int tid) {
+                                               cf* __restrict__ ldsB, const Twiddles& t, int tid) {
         cf* buf = ldsA;
         cf* other = ldsB;
 #pragma unroll
@@ -191,15 +240,10 @@ struct BlockFFT {
             if (p > 0) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) v[r] = buf[P::at(tid + r * NT)];
-                // twiddle W_{Ns*R}^(r*k), k = tid mod Ns
-                const int k = tid & (Ns - 1);
-                const int step = kTwiddleN / (Ns * R);
 #pragma unroll
-                for (int r = 1; r < R; ++r) {
-                    cf w = tw[(r * k * step) & (kTwiddleN - 1)];
-                    v[r] = INV ? cmulc(v[r], w) : cmul(v[r], w);
-                }
-                cf* t = buf; buf = other; other = t;
+                for (int r = 1; r < R; ++r)
+                    v[r] = INV ? cmulc(v[r], t.w[p - 1][r - 1]) : cmul(v[r], t.w[p - 1][r - 1]);
+                cf* tmp = buf; buf = other; other = tmp;
             }
             Butterfly<R, INV>::run(v);
             if (p < PASSES - 1) {

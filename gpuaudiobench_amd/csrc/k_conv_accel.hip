@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -99,24 +100,61 @@ __device__ __forceinline__ void partner_exchange(const cf (&z)[R], cf (&zp)[R],
     }
 }
 
-// W[k] = Z[k]*P[k] + Z'[k]*M[k]; the bank stores k <= N/2 only, the upper half
-// is the conjugate (P and M come from Hermitian spectra).
+// The bank stores k <= N/2 only; the upper half is the conjugate (P and M come
+// from Hermitian spectra).  Loads are split from the arithmetic so a caller can
+// issue them early and let HBM stream underneath a transform.
 template <int N, int R>
-__device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zp)[R],
-                                                 const float4* __restrict__ pm, int tid) {
+__device__ __forceinline__ void load_spectra(float4 (&c)[R], const float4* __restrict__ pm, int tid) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int k = tid + r * kThreads;
+        c[r] = pm[k > N / 2 ? N - k : k];
+    }
+}
+
+// W[k] = Z[k]*P[k] + Z'[k]*M[k]
+template <int N, int R>
+__device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zp)[R], const float4 (&c)[R],
+                                                 int tid) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int k = tid + r * kThreads;
         bool upper = k > N / 2;
-        float4 c = pm[upper ? N - k : k];
-        cf P = mk(c.x, upper ? -c.y : c.y);
-        cf M = mk(c.z, upper ? -c.w : c.w);
+        cf P = mk(c[r].x, upper ? -c[r].y : c[r].y);
+        cf M = mk(c[r].z, upper ? -c[r].w : c[r].w);
         z[r] = fft::cfma(zp[r], M, fft::cmul(z[r], P));
     }
 }
 
-template <bool STREAM, bool TAIL>
-__global__ __launch_bounds__(kThreads) void conv_overlap_save_kernel(
+// ABL is a diagnostic knob (builds with -DGAB_ABLATE only; outputs are then
+// wrong by design): 1 = memory traffic only, 2 = skip partition A's arithmetic,
+// 3 = skip partition B's arithmetic, 4 = B forward transform only,
+// 5 = B transforms without the spectral product / partner exchange.
+template <typename T>
+__device__ __forceinline__ void keep_alive(const T& v) {
+    const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("" ::"v"(f[i]));
+}
+
+#ifdef GAB_ABLATE
+// ABL == 6: lane 0 of every workgroup records s_memrealtime (100 MHz) at phase
+// boundaries into a buffer nothing else reads.
+__device__ unsigned long long g_conv_stamps[8 * 4096];
+#define GAB_STAMP(i)                                                                   \
+    do {                                                                               \
+        if constexpr (ABL == 6) {                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                         \
+            if (threadIdx.x == 0) g_conv_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                         \
+        }                                                                              \
+    } while (0)
+#else
+#define GAB_STAMP(i) do {} while (0)
+#endif
+
+template <bool STREAM, bool TAIL, int ABL = 0>
+__global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
     const cf* __restrict__ tw, int T, int head) {
@@ -132,60 +170,96 @@ __global__ __launch_bounds__(kThreads) void conv_overlap_save_kernel(
     float* const ha = hist + (size_t)ta * kSlots * kB;
     float* const hb = hist + (size_t)tb * kSlots * kB;   // only dereferenced if hasb
 
-    // ---- gather: history window (oldest block first) and the new block -----
+    // ---- gather.  Request order = need order: partition A's inputs (new block,
+    // previous block, its spectra) first, then the older history partition B
+    // works on, so A's transform runs while the rest of the window streams in.
+    GAB_STAMP(0);
     cf zb[16];
     cf za[4];
-    if constexpr (STREAM && TAIL) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int off = ((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid;
-            zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
-        }
-        za[0] = zb[14];
-        za[1] = zb[15];
-    } else if constexpr (STREAM) {
-        int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
+    float4 ca[4];
+    const float* xa = in + (size_t)ta * kB;
+    const float* xb = in + (size_t)tb * kB;
+    const float a0 = xa[tid], a1 = xa[tid + kThreads];
+    const float b0 = hasb ? xb[tid] : 0.0f, b1 = hasb ? xb[tid + kThreads] : 0.0f;
+    za[2] = mk(a0, b0);
+    za[3] = mk(a1, b1);
+    if constexpr (STREAM) {
+        const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
         za[0] = mk(ha[off], hasb ? hb[off] : 0.0f);
         za[1] = mk(ha[off + kThreads], hasb ? hb[off + kThreads] : 0.0f);
     } else {
         za[0] = mk(0.0f, 0.0f);
         za[1] = mk(0.0f, 0.0f);
     }
-    {
-        const float* xa = in + (size_t)ta * kB;
-        const float* xb = in + (size_t)tb * kB;
-        float a0 = xa[tid], a1 = xa[tid + kThreads];
-        float b0 = hasb ? xb[tid] : 0.0f, b1 = hasb ? xb[tid + kThreads] : 0.0f;
-        za[2] = mk(a0, b0);
-        za[3] = mk(a1, b1);
-        if constexpr (STREAM) {
-            // overwrite the oldest block (already in zb[0..1]) with the new one
-            ha[head * kB + tid] = a0;
-            ha[head * kB + kThreads + tid] = a1;
-            if (hasb) {
-                hb[head * kB + tid] = b0;
-                hb[head * kB + kThreads + tid] = b1;
-            }
+    load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
+    using FA = fft::BlockFFT<kNA, 4, false>;
+    using FB = fft::BlockFFT<kNB, 16, false>;
+    typename FA::Twiddles twa;
+    typename FB::Twiddles twb;
+    FA::load_twiddles(twa, tw, tid);
+    if constexpr (STREAM && TAIL) FB::load_twiddles(twb, tw, tid);
+    if constexpr (STREAM && TAIL) {
+#pragma unroll
+        for (int r = 0; r < 14; ++r) {
+            int off = ((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid;
+            zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
+        }
+        zb[14] = za[0];
+        zb[15] = za[1];
+    }
+    if constexpr (STREAM) {
+        // overwrite the oldest block (already requested into zb[0..1]) with the new one
+        ha[head * kB + tid] = a0;
+        ha[head * kB + kThreads + tid] = a1;
+        if (hasb) {
+            hb[head * kB + tid] = b0;
+            hb[head * kB + kThreads + tid] = b1;
         }
     }
 
     // ---- partition A ------------------------------------------------------
     // LDS hand-over between stages is barrier-free by construction: each stage
     // first writes the buffer whose last readers are already behind a barrier.
-    fft::BlockFFT<kNA, 4, false>::run(za, lds0, lds1, tw, tid);      // last reads: lds1
+    GAB_STAMP(1);
+    if constexpr (ABL == 1 || ABL == 2) {
+        keep_alive(ca);
+    } else {
+    fft::BlockFFT<kNA, 4, false>::run(za, lds0, lds1, twa, tid);     // last reads: lds1
     cf zpa[4];
     partner_exchange<kNA, 4>(za, zpa, lds0, tid);                     // writes/reads lds0
-    spectral_product<kNA, 4>(za, zpa, pmA + (size_t)q * kBinsA, tid);
-    fft::BlockFFT<kNA, 4, true>::run(za, lds1, lds0, tw, tid);       // first write lds1, last reads lds0
+    spectral_product<kNA, 4>(za, zpa, ca, tid);
+    fft::BlockFFT<kNA, 4, true>::run(za, lds1, lds0, twa, tid);   // first write lds1, last reads lds0
+    }
     float ya0 = za[2].x, yb0 = za[2].y, ya1 = za[3].x, yb1 = za[3].y;
+    GAB_STAMP(2);
 
     // ---- partition B ------------------------------------------------------
     if constexpr (STREAM && TAIL) {
-        fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, tw, tid);  // last reads: lds0
+        if constexpr (ABL == 1 || ABL == 3) {
+            float4 cb[16];
+            load_spectra<kNB, 16>(cb, pmB + (size_t)q * kBinsB, tid);
+            keep_alive(cb);
+        } else if constexpr (ABL == 4) {
+            fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, twb, tid);
+        } else if constexpr (ABL == 5) {
+            fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, twb, tid);
+            __syncthreads();
+            fft::BlockFFT<kNB, 16, true>::run(zb, lds0, lds1, twb, tid);
+        } else {
+        if constexpr (ABL == 6) keep_alive(zb);                       // stamp builds: history has landed
+        GAB_STAMP(3);
+        fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, twb, tid); // last reads: lds0
+        GAB_STAMP(4);
         cf zpb[16];
         partner_exchange<kNB, 16>(zb, zpb, lds1, tid);
-        spectral_product<kNB, 16>(zb, zpb, pmB + (size_t)q * kBinsB, tid);
-        fft::BlockFFT<kNB, 16, true>::run(zb, lds0, lds1, tw, tid);
+        // (prefetching these 64 registers ahead of the transform spills: measured 30 us)
+        float4 cb[16];
+        load_spectra<kNB, 16>(cb, pmB + (size_t)q * kBinsB, tid);
+        spectral_product<kNB, 16>(zb, zpb, cb, tid);
+        GAB_STAMP(5);
+        fft::BlockFFT<kNB, 16, true>::run(zb, lds0, lds1, twb, tid);
+        GAB_STAMP(6);
+        }
         ya0 += zb[14].x; yb0 += zb[14].y;
         ya1 += zb[15].x; yb1 += zb[15].y;
     }
@@ -201,6 +275,7 @@ __global__ __launch_bounds__(kThreads) void conv_overlap_save_kernel(
         o1[0] = ya1;
         if (hasb) { o0[1] = yb0; o1[1] = yb1; }
     }
+    GAB_STAMP(7);
 }
 
 // IR bank -> (P, M) spectra of both partitions.  d_ir is T x L track-major.
@@ -235,7 +310,9 @@ __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
         z[1] = tap(tid + kThreads);
         z[2] = mk(0.0f, 0.0f);
         z[3] = mk(0.0f, 0.0f);
-        fft::BlockFFT<kNA, 4, false>::run(z, lds0, lds1, tw, tid);
+        fft::BlockFFT<kNA, 4, false>::Twiddles t;
+        fft::BlockFFT<kNA, 4, false>::load_twiddles(t, tw, tid);
+        fft::BlockFFT<kNA, 4, false>::run(z, lds0, lds1, t, tid);
         partner_exchange<kNA, 4>(z, zp, lds0, tid);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -251,7 +328,9 @@ __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
             int m = tid + r * kThreads;
             z[r] = (m < kNB - kB) ? tap(kB + m) : mk(0.0f, 0.0f);
         }
-        fft::BlockFFT<kNB, 16, false>::run(z, lds0, lds1, tw, tid);
+        fft::BlockFFT<kNB, 16, false>::Twiddles t;
+        fft::BlockFFT<kNB, 16, false>::load_twiddles(t, tw, tid);
+        fft::BlockFFT<kNB, 16, false>::run(z, lds0, lds1, t, tid);
         partner_exchange<kNB, 16>(z, zp, lds0, tid);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -278,7 +357,9 @@ __global__ __launch_bounds__(kThreads) void fft_r2c_1024_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         z[r] = mk(xa[tid + r * kThreads], hasb ? xb[tid + r * kThreads] : 0.0f);
-    fft::BlockFFT<kNA, 4, false>::run(z, lds0, lds1, tw, tid);
+    fft::BlockFFT<kNA, 4, false>::Twiddles t;
+    fft::BlockFFT<kNA, 4, false>::load_twiddles(t, tw, tid);
+    fft::BlockFFT<kNA, 4, false>::run(z, lds0, lds1, t, tid);
     partner_exchange<kNA, 4>(z, zp, lds0, tid);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -447,6 +528,16 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
             if (!streaming)
                 gab::conv_overlap_save_kernel<false, false><<<grid, block, 0, s>>>(
                     d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
+#ifdef GAB_ABLATE
+            else if (p->tail && getenv("GAB_CONV_ABLATE")) {
+                const int a = atoi(getenv("GAB_CONV_ABLATE"));
+#define GAB_ABL_CASE(N) case N: gab::conv_overlap_save_kernel<true, true, N><<<grid, block, 0, s>>>( \
+                    d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head); break;
+                switch (a) { GAB_ABL_CASE(1) GAB_ABL_CASE(2) GAB_ABL_CASE(3) GAB_ABL_CASE(4) GAB_ABL_CASE(5) GAB_ABL_CASE(6)
+                             default: GAB_ABL_CASE(0) }
+#undef GAB_ABL_CASE
+            }
+#endif
             else if (p->tail)
                 gab::conv_overlap_save_kernel<true, true><<<grid, block, 0, s>>>(
                     d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
@@ -482,6 +573,14 @@ int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* histor
     if (history) *history = p->history_bytes;
     return GAB_OK;
 }
+
+#ifdef GAB_ABLATE
+// diagnostic builds only: copies the phase stamps of the last ABL==6 launch
+int gab_debug_conv_stamps(unsigned long long* h_out, int n) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_conv_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 int gab_fft_r2c_1024(const float* d_in, float* d_out, int tracks, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
