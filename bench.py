@@ -76,30 +76,20 @@ def main():
     T_total = T * world
 
     # ---- impulse-response bank: generated once, broadcast over RCCL -------------
-    if world > 1:
-        bank = torch.empty(T_total * L, dtype=torch.float32, device=dev)
-        if rank == 0:
-            bank.copy_(torch.from_numpy(gab.harness.conv_accel_ir(L, T_total)))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(bank, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-        ir_dev = bank.view(T_total, L)[rank * T:(rank + 1) * T].contiguous()
-        del bank
-    else:
-        bcast_ms = None
-        ir_dev = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).to(dev)
+    from gpuaudiobench_amd import sharding
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ir_dev = sharding.broadcast_ir_bank(L, T_total, rank, world, dev, dist if world > 1 else None)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None
 
     plan = gab.ConvPlan(T, B, L)
     plan.set_ir(ir_dev)
     spectra_bytes, history_bytes = plan.state_bytes()
 
     # ---- synthetic input: the reference's noise generator, this rank's channels --
-    inputs = []
-    for i in range(N_INPUT_BUFFERS):
-        flat = gab.harness.noise(T_total * B, seed=42 + i)       # flat track-major order
-        inputs.append(torch.from_numpy(flat.reshape(T_total, B)[rank * T:(rank + 1) * T].copy()).to(dev))
+    inputs = [torch.from_numpy(sharding.shard_noise(T_total, B, rank, world, seed=42 + i)).to(dev)
+              for i in range(N_INPUT_BUFFERS)]
     out = torch.empty(T * B, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()
 
