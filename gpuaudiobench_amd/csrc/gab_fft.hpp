@@ -24,28 +24,47 @@
 namespace gab {
 namespace fft {
 
-struct cf { float x, y; };
+// A complex value is a 64-bit register pair, so that gfx950's packed fp32 ops
+// (v_pk_add/mul/fma_f32, two lanes of arithmetic per instruction) apply directly.
+typedef float cf __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 __device__ __forceinline__ cf conj(cf a) { return mk(a.x, -a.y); }
+
+// Complex products as TWO packed instructions.  op_sel / op_sel_hi pick which half
+// of each 64-bit operand feeds the low / high result, neg_lo / neg_hi negate it —
+// so the (-b.y, b.x) operand needs no v_xor + v_mov, which is what hipcc emits
+// for the plain C expression (4 instructions per product, and this kernel is
+// VALU-bound).  The intermediate is early-clobber: it is written while a and b
+// are still live.
 // (a.x + i a.y)(b.x + i b.y)
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    return mk(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   // (-a.y*b.y, a.y*b.x)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"                             // + (a.x*b.x, a.x*b.y)
+        : "=&v"(r) : "v"(a), "v"(b));
+    return r;
 }
 // a * conj(b)
 __device__ __forceinline__ cf cmulc(cf a, cf b) {
-    return mk(__builtin_fmaf(a.x, b.x, a.y * b.y), __builtin_fmaf(a.y, b.x, -(a.x * b.y)));
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"                 // (a.y*b.y, a.y*b.x)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]"              // + (a.x*b.x, -a.x*b.y)
+        : "=&v"(r) : "v"(a), "v"(b));
+    return r;
 }
 // acc + a*b
 __device__ __forceinline__ cf cfma(cf a, cf b, cf acc) {
-    float re = __builtin_fmaf(a.x, b.x, acc.x);
-    re = __builtin_fmaf(-a.y, b.y, re);
-    float im = __builtin_fmaf(a.x, b.y, acc.y);
-    im = __builtin_fmaf(a.y, b.x, im);
-    return mk(re, im);
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+        : "=&v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
 }
+// a * a
+__device__ __forceinline__ cf csqr(cf a) { return cmul(a, a); }
 
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
@@ -169,9 +188,6 @@ struct Pad {
     __host__ __device__ static constexpr int size(int n) { return n + (n >> SH); }
 };
 
-__device__ __forceinline__ cf csqr(cf a) {
-    return mk(__builtin_fmaf(a.x, a.x, -(a.y * a.y)), 2.0f * (a.x * a.y));
-}
 
 // Twiddles of one transform shape: for every pass p >= 1 the R-1 factors
 // W_{Ns*R}^(r*k), r = 1..R-1, k = tid mod Ns.  They depend on tid only, so a
@@ -184,6 +200,13 @@ __device__ __forceinline__ cf csqr(cf a) {
 template <int R, int PASSES>
 struct TwiddleSet {
     cf w[PASSES > 1 ? PASSES - 1 : 1][R - 1];
+};
+
+// Cheaper in registers: only the base w^1 of each pass; powers are re-formed
+// inside every pass (R-2 complex products of VALU work per pass).
+template <int PASSES>
+struct TwiddleBases {
+    cf w[PASSES > 1 ? PASSES - 1 : 1];
 };
 
 template <int R>
@@ -218,6 +241,27 @@ struct BlockFFT {
     static_assert(kTwiddleN % N == 0, "twiddle table too small");
     using P = Pad<R>;
     using Twiddles = TwiddleSet<R, PASSES>;
+    using Bases = TwiddleBases<PASSES>;
+
+    __device__ static __forceinline__ void load_twiddles(Bases& t, const cf* __restrict__ tw, int tid) {
+#pragma unroll
+        for (int p = 1; p < PASSES; ++p) {
+            const int Ns = ipow(R, p);
+            t.w[p - 1] = tw[(tid & (Ns - 1)) * (kTwiddleN / (Ns * R))];
+        }
+    }
+
+    __device__ static __forceinline__ void pass_twiddles(const Twiddles& t, int p, cf (&w)[R - 1]) {
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) w[r] = t.w[p - 1][r];
+    }
+    __device__ static __forceinline__ void pass_twiddles(const Bases& t, int p, cf (&w)[R - 1]) {
+        cf b = t.w[p - 1];
+        // pin the power computation to this pass: hoisted to kernel entry it would
+        // hold (PASSES-1)*(R-1) complex registers live instead of PASSES-1
+        asm volatile("" : "+v"(b.x), "+v"(b.y));
+        powers_of<R>(b, w);
+    }
 
     __device__ static __forceinline__ void load_twiddles(Twiddles& t, const cf* __restrict__ tw, int tid) {
         cf base[PASSES];
@@ -230,29 +274,61 @@ struct BlockFFT {
         for (int p = 1; p < PASSES; ++p) powers_of<R>(base[p], t.w[p - 1]);
     }
 
+    // `active` lets a workgroup wider than NT threads run the transform on its first
+    // NT threads: the others skip the arithmetic but still meet every barrier.
+    template <class TW>
     __device__ static __forceinline__ void run(cf (&v)[R], cf* __restrict__ ldsA,
-                                               cf* __restrict__ ldsB, const Twiddles& t, int tid) {
+                                               cf* __restrict__ ldsB, const TW& tws, int tid,
+                                               bool active = true) {
+        // Opaque copy: stops the compiler from sharing LDS address arithmetic between
+        // separate transforms of one kernel, which it otherwise keeps live (and spills)
+        // across everything in between.
+        unsigned t = (unsigned)tid;
+        asm volatile("" : "+v"(t));
+        constexpr int SH = P::SH;
+        static_assert(NT % R == 0, "pad arithmetic assumes R | NT");
+        // Every LDS access below is ONE base register plus a compile-time offset:
+        // Pad(i) = i + (i >> SH) distributes over the strides used here because they
+        // are multiples of R = 2^SH (or, in pass 0, the R values of a thread are
+        // contiguous).  Recomputing Pad() per element costs ~3 integer VALU ops per
+        // access, ~100 per radix-16 pass, in a kernel that is VALU-bound.
+        const unsigned rd_base = t + (t >> SH);                 // Pad(t + r*NT) = rd_base + r*RD
+        constexpr unsigned RD = NT + (NT >> SH);
         cf* buf = ldsA;
         cf* other = ldsB;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int Ns = ipow(R, p);
             if (p > 0) {
+                if (active) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) v[r] = buf[P::at(tid + r * NT)];
+                    for (int r = 0; r < R; ++r) v[r] = buf[rd_base + r * RD];
+                    cf w[R - 1];
+                    pass_twiddles(tws, p, w);
 #pragma unroll
-                for (int r = 1; r < R; ++r)
-                    v[r] = INV ? cmulc(v[r], t.w[p - 1][r - 1]) : cmul(v[r], t.w[p - 1][r - 1]);
+                    for (int r = 1; r < R; ++r) v[r] = INV ? cmulc(v[r], w[r - 1]) : cmul(v[r], w[r - 1]);
+                }
                 cf* tmp = buf; buf = other; other = tmp;
             }
-            Butterfly<R, INV>::run(v);
+            if (active) Butterfly<R, INV>::run(v);
             if (p < PASSES - 1) {
-                const int base = (tid / Ns) * Ns * R + (tid & (Ns - 1));
+                if (active) {
+                    if (Ns >= R) {
+                        // base = (t / Ns) * Ns * R + (t mod Ns); Pad(base + r*Ns) = wb + r*WS
+                        const unsigned base = (t / (unsigned)Ns) * (unsigned)(Ns * R) + (t & (unsigned)(Ns - 1));
+                        const unsigned wb = base + (base >> SH);
+                        const unsigned WS = (unsigned)Ns + ((unsigned)Ns >> SH);
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    buf[P::at(base + r * Ns)] = v[Butterfly<R, INV>::out_slot(r)];
+                        for (int r = 0; r < R; ++r) buf[wb + r * WS] = v[Butterfly<R, INV>::out_slot(r)];
+                    } else {
+                        // Ns == 1: indices t*R + r, r < R  ->  Pad = t*(R+1) + r
+                        const unsigned wb = t * (unsigned)(R + 1);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) buf[wb + r] = v[Butterfly<R, INV>::out_slot(r)];
+                    }
+                }
                 __syncthreads();
-            } else {
+            } else if (active) {
                 // leave X[tid + r*NT] in v[r]
                 cf o[R];
 #pragma unroll

@@ -85,18 +85,23 @@ constexpr int kThreads = 256;
 using PadB = fft::Pad<16>;
 constexpr int kLdsHalf = PadB::size(kNB);       // cf entries per LDS buffer
 
-// Partner exchange: every thread publishes its R bins (k = tid + r*256) and
-// fetches conj(Z[(N-k) mod N]).
+// Partner exchange: every thread publishes its R bins (k = tid + r*N/R) and
+// fetches conj(Z[(N-k) mod N]).  Threads beyond N/R only meet the barrier.
 template <int N, int R>
 __device__ __forceinline__ void partner_exchange(const cf (&z)[R], cf (&zp)[R],
-                                                 cf* __restrict__ lds, int tid) {
+                                                 cf* __restrict__ lds, int tid, bool active = true) {
+    constexpr int NT = N / R;
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) lds[tid + r * kThreads] = z[r];
+        for (int r = 0; r < R; ++r) lds[tid + r * NT] = z[r];
+    }
     __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int k = tid + r * kThreads;
-        zp[r] = fft::conj(lds[(N - k) & (N - 1)]);
+        for (int r = 0; r < R; ++r) {
+            int k = tid + r * NT;
+            zp[r] = fft::conj(lds[(N - k) & (N - 1)]);
+        }
     }
 }
 
@@ -105,9 +110,10 @@ __device__ __forceinline__ void partner_exchange(const cf (&z)[R], cf (&zp)[R],
 // issue them early and let HBM stream underneath a transform.
 template <int N, int R>
 __device__ __forceinline__ void load_spectra(float4 (&c)[R], const float4* __restrict__ pm, int tid) {
+    constexpr int NT = N / R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int k = tid + r * kThreads;
+        int k = tid + r * NT;
         c[r] = pm[k > N / 2 ? N - k : k];
     }
 }
@@ -116,9 +122,10 @@ __device__ __forceinline__ void load_spectra(float4 (&c)[R], const float4* __res
 template <int N, int R>
 __device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zp)[R], const float4 (&c)[R],
                                                  int tid) {
+    constexpr int NT = N / R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int k = tid + r * kThreads;
+        int k = tid + r * NT;
         bool upper = k > N / 2;
         cf P = mk(c[r].x, upper ? -c[r].y : c[r].y);
         cf M = mk(c[r].z, upper ? -c[r].w : c[r].w);
@@ -126,10 +133,7 @@ __device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zp)[R], 
     }
 }
 
-// ABL is a diagnostic knob (builds with -DGAB_ABLATE only; outputs are then
-// wrong by design): 1 = memory traffic only, 2 = skip partition A's arithmetic,
-// 3 = skip partition B's arithmetic, 4 = B forward transform only,
-// 5 = B transforms without the spectral product / partner exchange.
+// Diagnostic builds (-DGAB_ABLATE) can stamp phase boundaries; see tools/stamp_conv.py.
 template <typename T>
 __device__ __forceinline__ void keep_alive(const T& v) {
     const float* f = reinterpret_cast<const float*>(&v);
@@ -153,6 +157,10 @@ __device__ unsigned long long g_conv_stamps[8 * 4096];
 #define GAB_STAMP(i) do {} while (0)
 #endif
 
+// (Tried and measured slower, so not kept: running partition B first in half of
+// the workgroups to de-phase the two workgroups that share a CU, 14.8 vs 14.0 us;
+// a 512-thread radix-8 form of this kernel, 16.6 us — kept below as
+// conv_overlap_save_wide_kernel behind GAB_CONV_WIDE=1 for comparison.)
 template <bool STREAM, bool TAIL, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
@@ -169,44 +177,50 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
 
     float* const ha = hist + (size_t)ta * kSlots * kB;
     float* const hb = hist + (size_t)tb * kSlots * kB;   // only dereferenced if hasb
+    using FA = fft::BlockFFT<kNA, 4, false>;
+    using FAi = fft::BlockFFT<kNA, 4, true>;
+    using FB = fft::BlockFFT<kNB, 16, false>;
+    using FBi = fft::BlockFFT<kNB, 16, true>;
 
-    // ---- gather.  Request order = need order: partition A's inputs (new block,
-    // previous block, its spectra) first, then the older history partition B
-    // works on, so A's transform runs while the rest of the window streams in.
     GAB_STAMP(0);
     cf zb[16];
     cf za[4];
     float4 ca[4];
-    const float* xa = in + (size_t)ta * kB;
-    const float* xb = in + (size_t)tb * kB;
-    const float a0 = xa[tid], a1 = xa[tid + kThreads];
-    const float b0 = hasb ? xb[tid] : 0.0f, b1 = hasb ? xb[tid + kThreads] : 0.0f;
-    za[2] = mk(a0, b0);
-    za[3] = mk(a1, b1);
-    if constexpr (STREAM) {
-        const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
-        za[0] = mk(ha[off], hasb ? hb[off] : 0.0f);
-        za[1] = mk(ha[off + kThreads], hasb ? hb[off + kThreads] : 0.0f);
-    } else {
-        za[0] = mk(0.0f, 0.0f);
-        za[1] = mk(0.0f, 0.0f);
-    }
-    load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
-    using FA = fft::BlockFFT<kNA, 4, false>;
-    using FB = fft::BlockFFT<kNB, 16, false>;
-    typename FA::Twiddles twa;
+    typename FA::Twiddles twa;      // all powers precomputed while the first loads are in flight
     typename FB::Twiddles twb;
-    FA::load_twiddles(twa, tw, tid);
-    if constexpr (STREAM && TAIL) FB::load_twiddles(twb, tw, tid);
-    if constexpr (STREAM && TAIL) {
-#pragma unroll
-        for (int r = 0; r < 14; ++r) {
-            int off = ((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid;
-            zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
+    float a0, a1, b0, b1;
+
+    // ---- requests, in the order this workgroup will need them ---------------------
+    auto request_a = [&]() {
+        const float* xa = in + (size_t)ta * kB;
+        const float* xb = in + (size_t)tb * kB;
+        a0 = xa[tid]; a1 = xa[tid + kThreads];
+        b0 = hasb ? xb[tid] : 0.0f; b1 = hasb ? xb[tid + kThreads] : 0.0f;
+        za[2] = mk(a0, b0);
+        za[3] = mk(a1, b1);
+        if constexpr (STREAM) {
+            const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
+            za[0] = mk(ha[off], hasb ? hb[off] : 0.0f);
+            za[1] = mk(ha[off + kThreads], hasb ? hb[off + kThreads] : 0.0f);
+        } else {
+            za[0] = mk(0.0f, 0.0f);
+            za[1] = mk(0.0f, 0.0f);
         }
-        zb[14] = za[0];
-        zb[15] = za[1];
-    }
+        load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
+        FA::load_twiddles(twa, tw, tid);
+    };
+    auto request_b = [&]() {
+        if constexpr (STREAM && TAIL) {
+            FB::load_twiddles(twb, tw, tid);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int off = ((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid;
+                zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
+            }
+        }
+    };
+    request_a();
+    request_b();
     if constexpr (STREAM) {
         // overwrite the oldest block (already requested into zb[0..1]) with the new one
         ha[head * kB + tid] = a0;
@@ -216,53 +230,41 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
             hb[head * kB + kThreads + tid] = b1;
         }
     }
-
-    // ---- partition A ------------------------------------------------------
-    // LDS hand-over between stages is barrier-free by construction: each stage
-    // first writes the buffer whose last readers are already behind a barrier.
     GAB_STAMP(1);
-    if constexpr (ABL == 1 || ABL == 2) {
-        keep_alive(ca);
-    } else {
-    fft::BlockFFT<kNA, 4, false>::run(za, lds0, lds1, twa, tid);     // last reads: lds1
-    cf zpa[4];
-    partner_exchange<kNA, 4>(za, zpa, lds0, tid);                     // writes/reads lds0
-    spectral_product<kNA, 4>(za, zpa, ca, tid);
-    fft::BlockFFT<kNA, 4, true>::run(za, lds1, lds0, twa, tid);   // first write lds1, last reads lds0
-    }
-    float ya0 = za[2].x, yb0 = za[2].y, ya1 = za[3].x, yb1 = za[3].y;
-    GAB_STAMP(2);
 
-    // ---- partition B ------------------------------------------------------
-    if constexpr (STREAM && TAIL) {
-        if constexpr (ABL == 1 || ABL == 3) {
+    // ---- stages.  LDS hand-over is barrier-free by construction: a stage called
+    // with (X, Y) first writes X and makes its last reads from X, so the next
+    // stage is called with (Y, X) — Y's last readers are behind a barrier by then.
+    float ya0 = 0.f, yb0 = 0.f, ya1 = 0.f, yb1 = 0.f;
+    auto part_a = [&](cf* X, cf* Y) {
+        FA::run(za, X, Y, twa, tid);                         // 5 passes: last reads Y
+        cf zpa[4];
+        partner_exchange<kNA, 4>(za, zpa, X, tid);
+        spectral_product<kNA, 4>(za, zpa, ca, tid);
+        FAi::run(za, Y, X, twa, tid);                        // last reads X
+        ya0 += za[2].x; yb0 += za[2].y;
+        ya1 += za[3].x; yb1 += za[3].y;
+    };
+    auto part_b = [&](cf* X, cf* Y) {
+        if constexpr (STREAM && TAIL) {
+            // request the spectra now; the scheduling barrier keeps the loads ahead of
+            // the transform so HBM streams underneath it
             float4 cb[16];
             load_spectra<kNB, 16>(cb, pmB + (size_t)q * kBinsB, tid);
-            keep_alive(cb);
-        } else if constexpr (ABL == 4) {
-            fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, twb, tid);
-        } else if constexpr (ABL == 5) {
-            fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, twb, tid);
-            __syncthreads();
-            fft::BlockFFT<kNB, 16, true>::run(zb, lds0, lds1, twb, tid);
-        } else {
-        if constexpr (ABL == 6) keep_alive(zb);                       // stamp builds: history has landed
-        GAB_STAMP(3);
-        fft::BlockFFT<kNB, 16, false>::run(zb, lds1, lds0, twb, tid); // last reads: lds0
-        GAB_STAMP(4);
-        cf zpb[16];
-        partner_exchange<kNB, 16>(zb, zpb, lds1, tid);
-        // (prefetching these 64 registers ahead of the transform spills: measured 30 us)
-        float4 cb[16];
-        load_spectra<kNB, 16>(cb, pmB + (size_t)q * kBinsB, tid);
-        spectral_product<kNB, 16>(zb, zpb, cb, tid);
-        GAB_STAMP(5);
-        fft::BlockFFT<kNB, 16, true>::run(zb, lds0, lds1, twb, tid);
-        GAB_STAMP(6);
+            __builtin_amdgcn_sched_barrier(0);
+            FB::run(zb, X, Y, twb, tid);                     // 3 passes: last reads Y
+            cf zpb[16];
+            partner_exchange<kNB, 16>(zb, zpb, X, tid);
+            spectral_product<kNB, 16>(zb, zpb, cb, tid);
+            FBi::run(zb, Y, X, twb, tid);                    // last reads X
+            ya0 += zb[14].x; yb0 += zb[14].y;
+            ya1 += zb[15].x; yb1 += zb[15].y;
         }
-        ya0 += zb[14].x; yb0 += zb[14].y;
-        ya1 += zb[15].x; yb1 += zb[15].y;
-    }
+    };
+    part_a(lds0, lds1);
+    GAB_STAMP(2);
+    part_b(lds1, lds0);
+    GAB_STAMP(6);
 
     // ---- scatter: sample-major out[T*s + t], s = tid and tid+256 -----------
     float* o0 = out + (size_t)T * tid + ta;
@@ -276,6 +278,121 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
         if (hasb) { o0[1] = yb0; o1[1] = yb1; }
     }
     GAB_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------
+// 512-thread variant: one channel pair per workgroup of 8 wavefronts.  The
+// 4096-point transforms are four radix-8 passes with 8 values per thread, which
+// halves every thread's serial instruction chain (a wavefront issues one VALU
+// op per four cycles at best), doubles the wavefronts per SIMD, and leaves room
+// to request the partition-B spectra before the forward transform.  Partition A
+// (1024 points) runs on the first 256 threads; the rest only meet its barriers.
+// ---------------------------------------------------------------------------
+constexpr int kWide = 512;
+using PadW = fft::Pad<8>;
+constexpr int kLdsHalfW = PadW::size(kNB);
+
+template <bool STREAM, bool TAIL>
+__global__ __launch_bounds__(kWide, 4) void conv_overlap_save_wide_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const float4* __restrict__ pmB,
+    const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalfW];
+    cf* const lds0 = lds;
+    cf* const lds1 = lds + kLdsHalfW;
+
+    const int tid = threadIdx.x;
+    const bool teamA = tid < kThreads;
+    const int q = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int ta = 2 * q, tb = 2 * q + 1;
+    const bool hasb = tb < T;
+    float* const ha = hist + (size_t)ta * kSlots * kB;
+    float* const hb = hist + (size_t)tb * kSlots * kB;
+
+    using FA = fft::BlockFFT<kNA, 4, false>;
+    using FAi = fft::BlockFFT<kNA, 4, true>;
+    using FB = fft::BlockFFT<kNB, 8, false>;
+    using FBi = fft::BlockFFT<kNB, 8, true>;
+    // ---- requests, in need order -------------------------------------------------
+    cf za[4];
+    float4 ca[4];
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (teamA) {
+        const float* xa = in + (size_t)ta * kB;
+        const float* xb = in + (size_t)tb * kB;
+        a0 = xa[tid]; a1 = xa[tid + kThreads];
+        if (hasb) { b0 = xb[tid]; b1 = xb[tid + kThreads]; }
+        za[2] = mk(a0, b0);
+        za[3] = mk(a1, b1);
+        if constexpr (STREAM) {
+            const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
+            za[0] = mk(ha[off], hasb ? hb[off] : 0.0f);
+            za[1] = mk(ha[off + kThreads], hasb ? hb[off + kThreads] : 0.0f);
+        } else {
+            za[0] = mk(0.0f, 0.0f);
+            za[1] = mk(0.0f, 0.0f);
+        }
+        load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
+    }
+    cf zb[8];
+    if constexpr (STREAM && TAIL) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {          // element tid + 512 r = sample tid of block r
+            int off = ((head + r) & (kSlots - 1)) * kB + tid;
+            zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
+        }
+    }
+    typename FA::Bases twa;
+    typename FB::Bases twb;
+    if (teamA) FA::load_twiddles(twa, tw, tid);
+    if constexpr (STREAM && TAIL) FB::load_twiddles(twb, tw, tid);
+    if constexpr (STREAM) {
+        if (teamA) {
+            // overwrite the oldest block (requested above into zb[0]) with the new one
+            ha[head * kB + tid] = a0;
+            ha[head * kB + kThreads + tid] = a1;
+            if (hasb) {
+                hb[head * kB + tid] = b0;
+                hb[head * kB + kThreads + tid] = b1;
+            }
+        }
+    }
+    // ---- partition A on the first four wavefronts ----------------------------------
+    FA::run(za, lds0, lds1, twa, tid, teamA);
+    cf zpa[4];
+    partner_exchange<kNA, 4>(za, zpa, lds0, tid, teamA);
+    if (teamA) spectral_product<kNA, 4>(za, zpa, ca, tid);
+    FAi::run(za, lds1, lds0, twa, tid, teamA);          // last reads: lds0
+    // ---- partition B on all eight ------------------------------------------------------
+    cf yB = mk(0.0f, 0.0f);
+    if constexpr (STREAM && TAIL) {
+        // four passes: a transform's LAST reads come from its FIRST buffer argument
+        FB::run(zb, lds1, lds0, twb, tid);                            // last reads: lds1
+        float4 cb[8];
+        load_spectra<kNB, 8>(cb, pmB + (size_t)q * kBinsB, tid);     // in flight across the exchange
+        cf zpb[8];
+        partner_exchange<kNB, 8>(zb, zpb, lds0, tid);                 // lds0: last read behind a barrier
+        spectral_product<kNB, 8>(zb, zpb, cb, tid);
+        FBi::run(zb, lds1, lds0, twb, tid);                           // last reads: lds1
+        yB = zb[7];                                                   // sample s = tid
+    }
+
+    // ---- hand partition A's 512 samples to their owners (s = tid) ----------------------
+    // lds0 was last read before the inverse's final barrier
+    if (teamA) {
+        lds0[tid] = za[2];
+        lds0[tid + kThreads] = za[3];
+    }
+    __syncthreads();
+    const cf yA = lds0[tid];
+    const float ya = yA.x + yB.x, yb = yA.y + yB.y;
+    float* o = out + (size_t)T * tid + ta;
+    if (hasb && (T & 1) == 0) {
+        *reinterpret_cast<float2*>(o) = make_float2(ya, yb);
+    } else {
+        o[0] = ya;
+        if (hasb) o[1] = yb;
+    }
 }
 
 // IR bank -> (P, M) spectra of both partitions.  d_ir is T x L track-major.
@@ -421,6 +538,7 @@ struct gab_conv_plan {
     bool fused = false;      // bufsize == 512 && ir_len <= 4096
     bool tail = false;       // ir_len > 512 (partition B present)
     bool ir_set = false;
+    bool wide = false;       // 512-thread radix-8 variant (measured slower: LDS-write bound)
     float4* pmA = nullptr;
     float4* pmB = nullptr;
     float* hist = nullptr;   // fused: [2*pairs][8][512]; fallback: two linear [T][hlen] buffers
@@ -443,6 +561,7 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
         p->pairs = (tracks + 1) / 2;
         p->fused = (bufsize == gab::kB && ir_len <= gab::kNB);
         p->tail = ir_len > gab::kB;
+        if (const char* v = getenv("GAB_CONV_WIDE")) p->wide = atoi(v) != 0;       // A/B switch for tuning
         try {
             if (p->fused) {
                 p->tw = gab::fft::device_twiddles();
@@ -525,25 +644,20 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
         const bool streaming = mode == GAB_CONV_STREAMING;
         if (p->fused) {
             dim3 grid(p->pairs), block(gab::kThreads);
+#define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head
             if (!streaming)
-                gab::conv_overlap_save_kernel<false, false><<<grid, block, 0, s>>>(
-                    d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
+                gab::conv_overlap_save_kernel<false, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
+            else if (!p->tail)
+                gab::conv_overlap_save_kernel<true, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
+            else if (p->wide)
+                gab::conv_overlap_save_wide_kernel<true, true><<<grid, dim3(gab::kWide), 0, s>>>(GAB_CONV_ARGS);
 #ifdef GAB_ABLATE
-            else if (p->tail && getenv("GAB_CONV_ABLATE")) {
-                const int a = atoi(getenv("GAB_CONV_ABLATE"));
-#define GAB_ABL_CASE(N) case N: gab::conv_overlap_save_kernel<true, true, N><<<grid, block, 0, s>>>( \
-                    d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head); break;
-                switch (a) { GAB_ABL_CASE(1) GAB_ABL_CASE(2) GAB_ABL_CASE(3) GAB_ABL_CASE(4) GAB_ABL_CASE(5) GAB_ABL_CASE(6)
-                             default: GAB_ABL_CASE(0) }
-#undef GAB_ABL_CASE
-            }
+            else if (getenv("GAB_CONV_ABLATE") && atoi(getenv("GAB_CONV_ABLATE")) == 6)
+                gab::conv_overlap_save_kernel<true, true, 6><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
 #endif
-            else if (p->tail)
-                gab::conv_overlap_save_kernel<true, true><<<grid, block, 0, s>>>(
-                    d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
             else
-                gab::conv_overlap_save_kernel<true, false><<<grid, block, 0, s>>>(
-                    d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
+                gab::conv_overlap_save_kernel<true, true><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
+#undef GAB_CONV_ARGS
             int rc = gab::launch_status("conv_overlap_save_kernel");
             if (rc) return rc;
             if (streaming) p->head = (p->head + 1) & (gab::kSlots - 1);
