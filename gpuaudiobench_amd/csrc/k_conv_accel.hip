@@ -108,13 +108,17 @@ __device__ __forceinline__ void partner_exchange(const cf (&z)[R], cf (&zp)[R],
 // The bank stores k <= N/2 only; the upper half is the conjugate (P and M come
 // from Hermitian spectra).  Loads are split from the arithmetic so a caller can
 // issue them early and let HBM stream underneath a transform.
+// Bin k = tid + r*NT lies in the stored half (k <= N/2) for r < R/2, in the
+// conjugate half for r > R/2; only r == R/2 depends on the thread (k = N/2 for tid 0).
 template <int N, int R>
 __device__ __forceinline__ void load_spectra(float4 (&c)[R], const float4* __restrict__ pm, int tid) {
     constexpr int NT = N / R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int k = tid + r * NT;
-        c[r] = pm[k > N / 2 ? N - k : k];
+        const int k = tid + r * NT;
+        if (r < R / 2) c[r] = pm[k];
+        else if (r > R / 2) c[r] = pm[N - k];
+        else c[r] = pm[tid == 0 ? k : N - k];
     }
 }
 
@@ -122,14 +126,15 @@ __device__ __forceinline__ void load_spectra(float4 (&c)[R], const float4* __res
 template <int N, int R>
 __device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zp)[R], const float4 (&c)[R],
                                                  int tid) {
-    constexpr int NT = N / R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int k = tid + r * NT;
-        bool upper = k > N / 2;
-        cf P = mk(c[r].x, upper ? -c[r].y : c[r].y);
-        cf M = mk(c[r].z, upper ? -c[r].w : c[r].w);
-        z[r] = fft::cfma(zp[r], M, fft::cmul(z[r], P));
+        cf P = mk(c[r].x, c[r].y), M = mk(c[r].z, c[r].w);
+        if (r > R / 2 || (r == R / 2 && tid != 0)) {       // conjugate half
+            // z*conj(P) + zp*conj(M)
+            z[r] = fft::cadd(fft::cmulc(z[r], P), fft::cmulc(zp[r], M));
+        } else {
+            z[r] = fft::cfma(zp[r], M, fft::cmul(z[r], P));
+        }
     }
 }
 
@@ -159,8 +164,9 @@ __device__ unsigned long long g_conv_stamps[8 * 4096];
 
 // (Tried and measured slower, so not kept: running partition B first in half of
 // the workgroups to de-phase the two workgroups that share a CU, 14.8 vs 14.0 us;
-// a 512-thread radix-8 form of this kernel, 16.6 us — kept below as
-// conv_overlap_save_wide_kernel behind GAB_CONV_WIDE=1 for comparison.)
+// a 512-thread radix-8 form of this kernel (8 values per thread, 4 passes), 16.6 us:
+// the transforms are bound by LDS write bandwidth and VALU throughput, not by the
+// per-thread instruction chain, and radix-8 needs a third exchange.)
 template <bool STREAM, bool TAIL, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     const int ta = 2 * q, tb = 2 * q + 1;
     const bool hasb = tb < T;
 
-    float* const ha = hist + (size_t)ta * kSlots * kB;
-    float* const hb = hist + (size_t)tb * kSlots * kB;   // only dereferenced if hasb
+    // history ring of this pair: [slot][sample] complex (channel a, channel b)
+    cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
     using FA = fft::BlockFFT<kNA, 4, false>;
     using FAi = fft::BlockFFT<kNA, 4, true>;
     using FB = fft::BlockFFT<kNB, 16, false>;
@@ -188,47 +194,38 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     float4 ca[4];
     typename FA::Twiddles twa;      // all powers precomputed while the first loads are in flight
     typename FB::Twiddles twb;
-    float a0, a1, b0, b1;
 
-    // ---- requests, in the order this workgroup will need them ---------------------
-    auto request_a = [&]() {
+    // ---- requests, in need order: partition A's inputs (new block, previous block,
+    // its spectra) first, then the older history partition B works on, so A's
+    // transform runs while the rest of the window streams in.
+    {
         const float* xa = in + (size_t)ta * kB;
         const float* xb = in + (size_t)tb * kB;
-        a0 = xa[tid]; a1 = xa[tid + kThreads];
-        b0 = hasb ? xb[tid] : 0.0f; b1 = hasb ? xb[tid + kThreads] : 0.0f;
-        za[2] = mk(a0, b0);
-        za[3] = mk(a1, b1);
-        if constexpr (STREAM) {
-            const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
-            za[0] = mk(ha[off], hasb ? hb[off] : 0.0f);
-            za[1] = mk(ha[off + kThreads], hasb ? hb[off + kThreads] : 0.0f);
-        } else {
-            za[0] = mk(0.0f, 0.0f);
-            za[1] = mk(0.0f, 0.0f);
-        }
-        load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
-        FA::load_twiddles(twa, tw, tid);
-    };
-    auto request_b = [&]() {
-        if constexpr (STREAM && TAIL) {
-            FB::load_twiddles(twb, tw, tid);
+        za[2] = mk(xa[tid], hasb ? xb[tid] : 0.0f);
+        za[3] = mk(xa[tid + kThreads], hasb ? xb[tid + kThreads] : 0.0f);
+    }
+    if constexpr (STREAM) {
+        const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
+        za[0] = hp[off];
+        za[1] = hp[off + kThreads];
+    } else {
+        za[0] = mk(0.0f, 0.0f);
+        za[1] = mk(0.0f, 0.0f);
+    }
+    load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
+    FA::load_twiddles(twa, tw, tid);
+    if constexpr (STREAM && TAIL) {
+        FB::load_twiddles(twb, tw, tid);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int off = ((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid;
-                zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
-            }
-        }
-    };
-    request_a();
-    request_b();
+        for (int r = 0; r < 14; ++r)
+            zb[r] = hp[((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid];
+        zb[14] = za[0];
+        zb[15] = za[1];
+    }
     if constexpr (STREAM) {
         // overwrite the oldest block (already requested into zb[0..1]) with the new one
-        ha[head * kB + tid] = a0;
-        ha[head * kB + kThreads + tid] = a1;
-        if (hasb) {
-            hb[head * kB + tid] = b0;
-            hb[head * kB + kThreads + tid] = b1;
-        }
+        hp[head * kB + tid] = za[2];
+        hp[head * kB + kThreads + tid] = za[3];
     }
     GAB_STAMP(1);
 
@@ -278,121 +275,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
         if (hasb) { o0[1] = yb0; o1[1] = yb1; }
     }
     GAB_STAMP(7);
-}
-
-// ---------------------------------------------------------------------------
-// 512-thread variant: one channel pair per workgroup of 8 wavefronts.  The
-// 4096-point transforms are four radix-8 passes with 8 values per thread, which
-// halves every thread's serial instruction chain (a wavefront issues one VALU
-// op per four cycles at best), doubles the wavefronts per SIMD, and leaves room
-// to request the partition-B spectra before the forward transform.  Partition A
-// (1024 points) runs on the first 256 threads; the rest only meet its barriers.
-// ---------------------------------------------------------------------------
-constexpr int kWide = 512;
-using PadW = fft::Pad<8>;
-constexpr int kLdsHalfW = PadW::size(kNB);
-
-template <bool STREAM, bool TAIL>
-__global__ __launch_bounds__(kWide, 4) void conv_overlap_save_wide_kernel(
-    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
-    const float4* __restrict__ pmA, const float4* __restrict__ pmB,
-    const cf* __restrict__ tw, int T, int head) {
-    __shared__ cf lds[2 * kLdsHalfW];
-    cf* const lds0 = lds;
-    cf* const lds1 = lds + kLdsHalfW;
-
-    const int tid = threadIdx.x;
-    const bool teamA = tid < kThreads;
-    const int q = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int ta = 2 * q, tb = 2 * q + 1;
-    const bool hasb = tb < T;
-    float* const ha = hist + (size_t)ta * kSlots * kB;
-    float* const hb = hist + (size_t)tb * kSlots * kB;
-
-    using FA = fft::BlockFFT<kNA, 4, false>;
-    using FAi = fft::BlockFFT<kNA, 4, true>;
-    using FB = fft::BlockFFT<kNB, 8, false>;
-    using FBi = fft::BlockFFT<kNB, 8, true>;
-    // ---- requests, in need order -------------------------------------------------
-    cf za[4];
-    float4 ca[4];
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-    if (teamA) {
-        const float* xa = in + (size_t)ta * kB;
-        const float* xb = in + (size_t)tb * kB;
-        a0 = xa[tid]; a1 = xa[tid + kThreads];
-        if (hasb) { b0 = xb[tid]; b1 = xb[tid + kThreads]; }
-        za[2] = mk(a0, b0);
-        za[3] = mk(a1, b1);
-        if constexpr (STREAM) {
-            const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
-            za[0] = mk(ha[off], hasb ? hb[off] : 0.0f);
-            za[1] = mk(ha[off + kThreads], hasb ? hb[off + kThreads] : 0.0f);
-        } else {
-            za[0] = mk(0.0f, 0.0f);
-            za[1] = mk(0.0f, 0.0f);
-        }
-        load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
-    }
-    cf zb[8];
-    if constexpr (STREAM && TAIL) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {          // element tid + 512 r = sample tid of block r
-            int off = ((head + r) & (kSlots - 1)) * kB + tid;
-            zb[r] = mk(ha[off], hasb ? hb[off] : 0.0f);
-        }
-    }
-    typename FA::Bases twa;
-    typename FB::Bases twb;
-    if (teamA) FA::load_twiddles(twa, tw, tid);
-    if constexpr (STREAM && TAIL) FB::load_twiddles(twb, tw, tid);
-    if constexpr (STREAM) {
-        if (teamA) {
-            // overwrite the oldest block (requested above into zb[0]) with the new one
-            ha[head * kB + tid] = a0;
-            ha[head * kB + kThreads + tid] = a1;
-            if (hasb) {
-                hb[head * kB + tid] = b0;
-                hb[head * kB + kThreads + tid] = b1;
-            }
-        }
-    }
-    // ---- partition A on the first four wavefronts ----------------------------------
-    FA::run(za, lds0, lds1, twa, tid, teamA);
-    cf zpa[4];
-    partner_exchange<kNA, 4>(za, zpa, lds0, tid, teamA);
-    if (teamA) spectral_product<kNA, 4>(za, zpa, ca, tid);
-    FAi::run(za, lds1, lds0, twa, tid, teamA);          // last reads: lds0
-    // ---- partition B on all eight ------------------------------------------------------
-    cf yB = mk(0.0f, 0.0f);
-    if constexpr (STREAM && TAIL) {
-        // four passes: a transform's LAST reads come from its FIRST buffer argument
-        FB::run(zb, lds1, lds0, twb, tid);                            // last reads: lds1
-        float4 cb[8];
-        load_spectra<kNB, 8>(cb, pmB + (size_t)q * kBinsB, tid);     // in flight across the exchange
-        cf zpb[8];
-        partner_exchange<kNB, 8>(zb, zpb, lds0, tid);                 // lds0: last read behind a barrier
-        spectral_product<kNB, 8>(zb, zpb, cb, tid);
-        FBi::run(zb, lds1, lds0, twb, tid);                           // last reads: lds1
-        yB = zb[7];                                                   // sample s = tid
-    }
-
-    // ---- hand partition A's 512 samples to their owners (s = tid) ----------------------
-    // lds0 was last read before the inverse's final barrier
-    if (teamA) {
-        lds0[tid] = za[2];
-        lds0[tid + kThreads] = za[3];
-    }
-    __syncthreads();
-    const cf yA = lds0[tid];
-    const float ya = yA.x + yB.x, yb = yA.y + yB.y;
-    float* o = out + (size_t)T * tid + ta;
-    if (hasb && (T & 1) == 0) {
-        *reinterpret_cast<float2*>(o) = make_float2(ya, yb);
-    } else {
-        o[0] = ya;
-        if (hasb) o[1] = yb;
-    }
 }
 
 // IR bank -> (P, M) spectra of both partitions.  d_ir is T x L track-major.
@@ -538,10 +420,9 @@ struct gab_conv_plan {
     bool fused = false;      // bufsize == 512 && ir_len <= 4096
     bool tail = false;       // ir_len > 512 (partition B present)
     bool ir_set = false;
-    bool wide = false;       // 512-thread radix-8 variant (measured slower: LDS-write bound)
     float4* pmA = nullptr;
     float4* pmB = nullptr;
-    float* hist = nullptr;   // fused: [2*pairs][8][512]; fallback: two linear [T][hlen] buffers
+    float* hist = nullptr;   // fused: [pairs][8 slots][512] complex (ch a, ch b); fallback: two linear [T][hlen]
     float* hist_alt = nullptr;
     float* ir_copy = nullptr;   // fallback path keeps the time-domain taps
     int hlen = 0;
@@ -561,7 +442,6 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
         p->pairs = (tracks + 1) / 2;
         p->fused = (bufsize == gab::kB && ir_len <= gab::kNB);
         p->tail = ir_len > gab::kB;
-        if (const char* v = getenv("GAB_CONV_WIDE")) p->wide = atoi(v) != 0;       // A/B switch for tuning
         try {
             if (p->fused) {
                 p->tw = gab::fft::device_twiddles();
@@ -649,8 +529,6 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
                 gab::conv_overlap_save_kernel<false, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
             else if (!p->tail)
                 gab::conv_overlap_save_kernel<true, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
-            else if (p->wide)
-                gab::conv_overlap_save_wide_kernel<true, true><<<grid, dim3(gab::kWide), 0, s>>>(GAB_CONV_ARGS);
 #ifdef GAB_ABLATE
             else if (getenv("GAB_CONV_ABLATE") && atoi(getenv("GAB_CONV_ABLATE")) == 6)
                 gab::conv_overlap_save_kernel<true, true, 6><<<grid, block, 0, s>>>(GAB_CONV_ARGS);

@@ -208,7 +208,7 @@ def test_conv_accel_linearity_and_shard_equality(gab, orc):
     xs = [orc.noise(T * B, seed=s) for s in (1, 2)]
     for xv in (xs[0], xs[1], (0.5 * xs[0] + xs[1]).astype(np.float32)):
         full.reset()
-        for _ in range(3):                                    # with history in play
+        for _ in range(9):                                    # history window full (steady state)
             y = host(full.process(dev(xv), mode=gab.CONV_STREAMING))
         outs.append(y.astype(np.float64))
     lin = np.abs(outs[2] - (0.5 * outs[0] + outs[1])).max() / np.abs(outs[2]).max()
@@ -219,7 +219,7 @@ def test_conv_accel_linearity_and_shard_equality(gab, orc):
     shard = gab.ConvPlan(hi - lo, B, L)
     shard.set_ir(dev(ir_slice))
     xs0 = xs[0].reshape(T, B)[lo:hi].ravel()
-    for _ in range(3):
+    for _ in range(9):
         ys = host(shard.process(dev(xs0), mode=gab.CONV_STREAMING))
     assert np.array_equal(bits(ys.reshape(B, hi - lo)), bits(outs[0].astype(np.float32).reshape(B, T)[:, lo:hi]))
     full.close()
