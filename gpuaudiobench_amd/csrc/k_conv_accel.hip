@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
             cf zpb[16];
             partner_exchange<kNB, 16>(zb, zpb, X, tid);
             spectral_product<kNB, 16>(zb, zpb, cb, tid);
-            FBi::run(zb, Y, X, twb, tid);                    // last reads X
+            FBi::template run<typename FB::Twiddles, true>(zb, Y, X, twb, tid);   // last reads X; only [14],[15]
             ya0 += zb[14].x; yb0 += zb[14].y;
             ya1 += zb[15].x; yb1 += zb[15].y;
         }
