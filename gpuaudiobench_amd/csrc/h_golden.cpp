@@ -175,9 +175,13 @@ void fdtd3d(const gab_fdtd_params& P, float* p, float* vx, float* vy, float* vz,
     const size_t rcv = P.receiver_z * sxy + static_cast<size_t>(P.receiver_y) * nx + P.receiver_x;
     for (int s = first_sample; s < first_sample + n_samples; ++s)
         for (int step = 0; step < P.steps_per_sample; ++step) {
-            if (step == 0)
+            if (step == 0) {
+                // atomicAdd order is unspecified in the reference; fixed as: sum in track order, add once
+                float acc = 0.0f;
                 for (int t = 0; t < T; ++t)
-                    p[src] += in[static_cast<size_t>(t) * B + s] * BenchmarkConstants::FDTD3D_SOURCE_SCALE;
+                    acc += in[static_cast<size_t>(t) * B + s] * BenchmarkConstants::FDTD3D_SOURCE_SCALE;
+                p[src] += acc;
+            }
             for (int z = 0; z < nz; ++z)
                 for (int y = 0; y < ny; ++y) {
                     const float* pr = p + z * sxy + static_cast<size_t>(y) * nx;

@@ -455,8 +455,8 @@ void orc_fdtd_placeholder(const float* in, float* out, int tracks, int bufsize) 
 }
 
 /* Restates the four kernels (bench_fdtd3d.cu:14-139) in the order of
- * runFDTD3DTimeStep (:384-438).  The atomicAdd injection is summed in track
- * order.  `fused` selects the single-rounding a-=c*d nvcc emits for the
+ * runFDTD3DTimeStep (:384-438).  The atomicAdd injection is fixed to "sum the
+ * tracks in order, add the sum once".  `fused` selects the single-rounding a-=c*d nvcc emits for the
  * kernels (-fmad=true); fused==0 is the two-rounding host form.             */
 void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
               float* vz, const float* in, float* out, int tracks, int bufsize,
@@ -470,9 +470,13 @@ void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
 
     for (int s = first_sample; s < first_sample + n_samples; ++s) {
         for (int step = 0; step < P->steps_per_sample; ++step) {
-            if (step == 0)
-                for (int t = 0; t < tracks; ++t)
-                    p[src] += in[(size_t)t * bufsize + s] * 0.1f;
+            if (step == 0) {
+                /* the reference's atomicAdd order is unspecified; fixed here as: scaled
+                 * samples summed in track order, the sum added to the cell once */
+                float acc = 0.0f;
+                for (int t = 0; t < tracks; ++t) acc += in[(size_t)t * bufsize + s] * 0.1f;
+                p[src] += acc;
+            }
 
             /* velocity (interior faces) */
             for (int z = 0; z < nz; ++z)
