@@ -76,6 +76,7 @@ PROTOTYPES = {
     "gab_gainstats": (_I, [_P, _P, _P, _I, _I, _F, _P]),
     "gab_datatransfer": (_I, [_P, _P, _I, _I, _P]),
     "gab_iir": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
+    "gab_iir_sequential": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_conv1d": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gab_rndmem": (_I, [_P, _P, _P, _I, _I, _P]),
     "gab_modal": (_I, [_P, _P, _I, _I, _I, _P]),

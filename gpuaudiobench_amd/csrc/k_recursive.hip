@@ -9,6 +9,8 @@
 // delay-line cells.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "gab_common.hpp"
 
 namespace gab {
@@ -23,50 +25,210 @@ struct BiquadCoeffs { float b0, b1, b2, a1, a2; };
 
 constexpr int kIirTracks = 64;    // tracks per workgroup = one wavefront of recurrences
 constexpr int kIirChunk = 64;     // samples staged per step
+constexpr int kIirPitch = 68;     // row pitch in floats: 16-byte aligned rows, conflict-free b128 access
 
+// Wave 0 owns the recurrences (lane = track); all four waves move rows between
+// HBM and LDS with 256-byte coalesced accesses.  A lane pulls its 64-sample row
+// chunk into registers with 16 ds_read_b128, runs the 64 steps with nothing but
+// VALU on the dependency chain, and writes the chunk back — an LDS round trip
+// inside the loop costs ~10x the arithmetic.  Tiles are double-buffered so the
+// next chunk streams in while this one is filtered.
 __global__ __launch_bounds__(256) void iir_biquad_kernel(const float* __restrict__ in,
                                                         float* __restrict__ out,
                                                         float* __restrict__ state,
                                                         BiquadCoeffs c, int T, int B) {
-    __shared__ float tile[kIirTracks][kIirChunk + 1];
+    __shared__ __attribute__((aligned(16))) float tile[2][kIirTracks][kIirPitch];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t0 = blockIdx.x * kIirTracks;
     const int my_track = t0 + lane;
+    const bool owner = (w == 0) && (my_track < T);
     float z1 = 0.0f, z2 = 0.0f;
-    if (w == 0 && my_track < T) {
+    if (owner) {
         z1 = state[2 * my_track];
         z2 = state[2 * my_track + 1];
     }
-    for (int s0 = 0; s0 < B; s0 += kIirChunk) {
-        // stage: each wave loads rows (tracks), lanes run along samples
-        for (int r = w; r < kIirTracks; r += 4) {
-            int t = t0 + r, s = s0 + lane;
-            if (t < T && s < B) tile[r][lane] = in[(size_t)t * B + s];
+    // Row movers: 16 rows per wave, all requests issued before the first is consumed.
+    auto load_rows = [&](int buf, int s0, int first, int step) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int r = first + k * step, t = t0 + r, s = s0 + lane;
+            v[k] = (r < kIirTracks && t < T && s < B) ? in[(size_t)t * B + s] : 0.0f;
         }
-        __syncthreads();
-        if (w == 0 && my_track < T) {
-            const int n = (B - s0) < kIirChunk ? (B - s0) : kIirChunk;
-            for (int i = 0; i < n; ++i) {
-                float x = tile[lane][i];
-                float wv = __fsub_rn(__fsub_rn(x, __fmul_rn(c.a1, z1)), __fmul_rn(c.a2, z2));
-                float y = __fadd_rn(__fadd_rn(__fmul_rn(c.b0, wv), __fmul_rn(c.b1, z1)),
-                                    __fmul_rn(c.b2, z2));
-                z2 = z1;
-                z1 = wv;
-                tile[lane][i] = y;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int r = first + k * step;
+            if (r < kIirTracks) tile[buf][r][lane] = v[k];
+        }
+    };
+    auto store_rows = [&](int buf, int s0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int r = w + 4 * k, t = t0 + r, s = s0 + lane;
+            if (t < T && s < B) out[(size_t)t * B + s] = tile[buf][r][lane];
+        }
+    };
+    const int nchunks = (B + kIirChunk - 1) / kIirChunk;
+    load_rows(0, 0, w, 4);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1, s0 = ch * kIirChunk;
+        const int n = (B - s0) < kIirChunk ? (B - s0) : kIirChunk;     // valid samples in this chunk
+        if (w == 0) {
+            if (owner) {
+                float x[kIirChunk];
+                float4* row = reinterpret_cast<float4*>(&tile[buf][lane][0]);
+#pragma unroll
+                for (int i = 0; i < kIirChunk / 4; ++i) {
+                    float4 v = row[i];
+                    x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+                }
+#pragma unroll
+                for (int i = 0; i < kIirChunk; ++i) {
+                    if (i < n) {     // wave-uniform: a ragged last chunk must not run on padding
+                        // golden's operation order, one rounding per operation (bench_iir.cu:170-197)
+                        float wv = __fsub_rn(__fsub_rn(x[i], __fmul_rn(c.a1, z1)), __fmul_rn(c.a2, z2));
+                        float y = __fadd_rn(__fadd_rn(__fmul_rn(c.b0, wv), __fmul_rn(c.b1, z1)),
+                                            __fmul_rn(c.b2, z2));
+                        z2 = z1;
+                        z1 = wv;
+                        x[i] = y;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kIirChunk / 4; ++i)
+                    row[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
             }
+        } else if (ch + 1 < nchunks) {
+            // the other three waves fetch the next chunk meanwhile (rows w-1, w+2, ...)
+            load_rows(buf ^ 1, s0 + kIirChunk, w - 1, 3);
+            load_rows(buf ^ 1, s0 + kIirChunk, w - 1 + 48, 3);
         }
         __syncthreads();
-        for (int r = w; r < kIirTracks; r += 4) {
-            int t = t0 + r, s = s0 + lane;
-            if (t < T && s < B) out[(size_t)t * B + s] = tile[r][lane];
-        }
+        store_rows(buf, s0);
         __syncthreads();
     }
-    if (w == 0 && my_track < T) {
+    if (owner) {
         state[2 * my_track] = z1;
         state[2 * my_track + 1] = z2;
     }
+}
+
+// ---------------------------------------------------------------------------
+// IIR, wave-scan form: one wavefront per track, lane l owns samples [l*M, l*M+M).
+//   1. every lane runs the recurrence over its M samples from ZERO state (lane 0
+//      from the carried state), giving w_local and its outgoing state c_l;
+//   2. the state entering lane l is S_l = A^M S_{l-1} + c_{l-1}: an affine scan
+//      with one constant matrix, done in 6 Kogge-Stone steps of __shfl_up with
+//      the precomputed powers A^(M*2^k);
+//   3. w[i] = w_local[i] + (row i of the homogeneous response) . S_l;
+//   4. y[n] = b0 w[n] + b1 w[n-1] + b2 w[n-2] element-wise.
+// 512 samples cost ~130 VALU ops per lane instead of a 512-step serial chain.
+// Rounding differs from the sequential golden by re-association only; the filter's
+// poles (radius sqrt(a2) = 0.41) make A^M tiny, so the result stays within ~1e-7.
+// ---------------------------------------------------------------------------
+struct IirScanConsts {
+    float alpha[16], beta[16];   // w-response of sample i to an incoming state (z1, z2)
+    float p[6][4];               // (A^M)^(2^k), row-major 2x2, acting on (z1, z2)
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void iir_scan_kernel(const float* __restrict__ in,
+                                                      float* __restrict__ out,
+                                                      float* __restrict__ state, BiquadCoeffs c,
+                                                      IirScanConsts k, int T) {
+    constexpr int B = 64 * M;
+    const int lane = threadIdx.x & 63;
+    const int track = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (track >= T) return;
+    const float* x = in + (size_t)track * B + lane * M;
+    float xv[M], w[M];
+    if constexpr (M % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < M / 4; ++i) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            xv[4 * i] = v.x; xv[4 * i + 1] = v.y; xv[4 * i + 2] = v.z; xv[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) xv[i] = x[i];
+    }
+    // 1. local pass
+    float z1 = 0.0f, z2 = 0.0f;
+    if (lane == 0) { z1 = state[2 * track]; z2 = state[2 * track + 1]; }
+    const float z1_in0 = z1, z2_in0 = z2;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        float wv = xv[i] - c.a1 * z1 - c.a2 * z2;
+        z2 = z1; z1 = wv; w[i] = wv;
+    }
+    // 2. inclusive scan of outgoing states: E_l = c_l + A^M E_{l-1}
+    float e1 = z1, e2 = z2;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = 1 << s;
+        float u1 = __shfl_up(e1, d, 64), u2 = __shfl_up(e2, d, 64);
+        if (lane >= d) {
+            e1 += k.p[s][0] * u1 + k.p[s][1] * u2;
+            e2 += k.p[s][2] * u1 + k.p[s][3] * u2;
+        }
+    }
+    // state entering this lane (lane 0 already started from the carried state)
+    float s1 = __shfl_up(e1, 1, 64), s2 = __shfl_up(e2, 1, 64);
+    if (lane == 0) { s1 = 0.0f; s2 = 0.0f; }
+    // 3. homogeneous correction
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] += k.alpha[i] * s1 + k.beta[i] * s2;
+    // 4. output taps need w[n-1], w[n-2]: the previous lane's last two (or the carried state)
+    float p1 = __shfl_up(w[M - 1], 1, 64);
+    float p2 = (M >= 2) ? __shfl_up(w[M >= 2 ? M - 2 : 0], 1, 64) : __shfl_up(w[0], 2, 64);
+    const float carried_z1 = __shfl(z1_in0, 0, 64);      // all lanes: lane 0's incoming z1
+    if (lane == 0) { p1 = z1_in0; p2 = z2_in0; }
+    if (M == 1 && lane == 1) p2 = carried_z1;
+    float y[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float wm1 = (i >= 1) ? w[i - 1] : p1;
+        const float wm2 = (i >= 2) ? w[i - 2] : (i == 1 ? p1 : p2);
+        y[i] = c.b0 * w[i] + c.b1 * wm1 + c.b2 * wm2;
+    }
+    float* o = out + (size_t)track * B + lane * M;
+    if constexpr (M % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < M / 4; ++i)
+            reinterpret_cast<float4*>(o)[i] = make_float4(y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) o[i] = y[i];
+    }
+    if (lane == 63) {
+        state[2 * track] = w[M - 1];
+        state[2 * track + 1] = (M >= 2) ? w[M >= 2 ? M - 2 : 0] : p1;
+    }
+}
+
+// Host: constants of the scan for M samples per lane, computed in float64.
+inline IirScanConsts make_scan_consts(const BiquadCoeffs& c, int M) {
+    IirScanConsts k{};
+    // state map per sample on (z1, z2): z1' = -a1 z1 - a2 z2 (+x), z2' = z1
+    double A[4] = {-(double)c.a1, -(double)c.a2, 1.0, 0.0};
+    double P[4] = {1, 0, 0, 1};
+    auto mul = [](const double* X, const double* Y, double* Z) {
+        double r[4] = {X[0] * Y[0] + X[1] * Y[2], X[0] * Y[1] + X[1] * Y[3],
+                       X[2] * Y[0] + X[3] * Y[2], X[2] * Y[1] + X[3] * Y[3]};
+        for (int i = 0; i < 4; ++i) Z[i] = r[i];
+    };
+    for (int i = 0; i < M; ++i) {
+        mul(A, P, P);                       // P = A^(i+1); its first row is w[i]'s response
+        k.alpha[i] = (float)P[0];
+        k.beta[i] = (float)P[1];
+    }
+    double Q[4] = {P[0], P[1], P[2], P[3]}; // A^M
+    for (int s = 0; s < 6; ++s) {
+        for (int i = 0; i < 4; ++i) k.p[s][i] = (float)Q[i];
+        mul(Q, Q, Q);
+    }
+    return k;
 }
 
 // ---------------------------------------------------------------------------
@@ -103,10 +265,26 @@ __global__ __launch_bounds__(kConvTile) void conv1d_direct_kernel(const float* _
         // output i0+tid at tap j0+jj reads flat index flat0+tid-j0-jj = wbase + (nj-1) + tid - jj
         const long first_valid = flat0 + tid - j0;   // flat index at jj = 0
         const int top = nj - 1 + tid;
-        for (int jj = 0; jj < nj; ++jj) {
+        // The sum is a strictly ordered chain of roundings (that is what makes it
+        // bit-identical to the golden), so the only freedom is to keep everything
+        // else off that chain: fetch 8 taps and 8 samples per trip, then add in order.
+        int jj = 0;
+        for (; jj + 8 <= nj; jj += 8) {
+            float h[8], x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { h[k] = taps[jj + k]; x[k] = win[top - jj - k]; }
+            if (first_valid - (jj + 7) >= 0) {       // whole group in range (all but the very start)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = __fadd_rn(acc, __fmul_rn(h[k], x[k]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (first_valid - (jj + k) >= 0) acc = __fadd_rn(acc, __fmul_rn(h[k], x[k]));
+            }
+        }
+        for (; jj < nj; ++jj)
             if (first_valid - jj >= 0)               // golden skips taps that fall before sample 0
                 acc = __fadd_rn(acc, __fmul_rn(taps[jj], win[top - jj]));
-        }
         __syncthreads();
     }
     if (i0 + tid < B) out[(size_t)t * B + i0 + tid] = acc;
@@ -191,19 +369,36 @@ __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ w
     *Bk = b;
 }
 
+// One wavefront per output sample.  Lanes test 64 waveguides at a time for "does
+// sample s land on your output tap"; the (few) that do are added in waveguide
+// order via ballot + readlane, so the sum is the golden's ordered sum without a
+// serial scan over every waveguide.
 __global__ __launch_bounds__(256) void dwg_mix_kernel(const WG* __restrict__ wgs,
                                                      const float* __restrict__ ws,
                                                      float* __restrict__ out, int n_wg, int B,
                                                      int out_tracks) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= B) return;
     float acc = 0.0f;
     const int n = n_wg < out_tracks ? n_wg : out_tracks;
-    for (int g = 0; g < n; ++g) {
-        const int L = wgs[g].length;
-        if ((wgs[g].writePos + s) % L == wgs[g].outTap) acc = __fadd_rn(acc, ws[(size_t)g * B + s]);
+    for (int g0 = 0; g0 < n; g0 += 64) {
+        const int g = g0 + lane;
+        bool hit = false;
+        float v = 0.0f;
+        if (g < n) {
+            const int L = wgs[g].length;
+            hit = ((wgs[g].writePos + s) % L) == wgs[g].outTap;
+            if (hit) v = ws[(size_t)g * B + s];
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            acc = __fadd_rn(acc, __shfl(v, src, 64));
+            m &= m - 1;
+        }
     }
-    out[s] = acc;
+    if (lane == 0) out[s] = acc;
 }
 
 }  // namespace
@@ -211,16 +406,41 @@ __global__ __launch_bounds__(256) void dwg_mix_kernel(const WG* __restrict__ wgs
 
 extern "C" {
 
-int gab_iir(const float* d_in, float* d_out, const float* coeffs, float* d_state, int tracks,
-            int bufsize, gab_stream_t stream) {
+int gab_iir_sequential(const float* d_in, float* d_out, const float* coeffs, float* d_state,
+                       int tracks, int bufsize, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
-        if (!d_in || !d_out || !coeffs || !d_state) return gab::bad_arg("gab_iir: null pointer");
-        if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_iir: tracks and bufsize must be > 0");
+        if (!d_in || !d_out || !coeffs || !d_state) return gab::bad_arg("gab_iir_sequential: null pointer");
+        if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_iir_sequential: tracks and bufsize must be > 0");
         gab::BiquadCoeffs c{coeffs[0], coeffs[1], coeffs[2], coeffs[3], coeffs[4]};
         dim3 grid((tracks + gab::kIirTracks - 1) / gab::kIirTracks);
         gab::iir_biquad_kernel<<<grid, 256, 0, gab::as_stream(stream)>>>(d_in, d_out, d_state, c,
                                                                            tracks, bufsize);
         return gab::launch_status("iir_biquad_kernel");
+    });
+}
+
+int gab_iir(const float* d_in, float* d_out, const float* coeffs, float* d_state, int tracks,
+            int bufsize, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!d_in || !d_out || !coeffs || !d_state) return gab::bad_arg("gab_iir: null pointer");
+        if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_iir: tracks and bufsize must be > 0");
+        const int m = bufsize / 64;
+        const bool scan_ok = bufsize % 64 == 0 && (m == 1 || m == 2 || m == 4 || m == 8 || m == 16) &&
+                             (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0 &&
+                             (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+        if (!scan_ok) return gab_iir_sequential(d_in, d_out, coeffs, d_state, tracks, bufsize, stream);
+        gab::BiquadCoeffs c{coeffs[0], coeffs[1], coeffs[2], coeffs[3], coeffs[4]};
+        const gab::IirScanConsts k = gab::make_scan_consts(c, m);
+        dim3 grid((tracks + 3) / 4);
+        hipStream_t s = gab::as_stream(stream);
+        switch (m) {
+            case 1: gab::iir_scan_kernel<1><<<grid, 256, 0, s>>>(d_in, d_out, d_state, c, k, tracks); break;
+            case 2: gab::iir_scan_kernel<2><<<grid, 256, 0, s>>>(d_in, d_out, d_state, c, k, tracks); break;
+            case 4: gab::iir_scan_kernel<4><<<grid, 256, 0, s>>>(d_in, d_out, d_state, c, k, tracks); break;
+            case 8: gab::iir_scan_kernel<8><<<grid, 256, 0, s>>>(d_in, d_out, d_state, c, k, tracks); break;
+            default: gab::iir_scan_kernel<16><<<grid, 256, 0, s>>>(d_in, d_out, d_state, c, k, tracks); break;
+        }
+        return gab::launch_status("iir_scan_kernel");
     });
 }
 
@@ -264,8 +484,8 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
         }
         int rc = gab::launch_status("dwg kernel");
         if (rc) return rc;
-        gab::dwg_mix_kernel<<<(bufsize + 255) / 256, 256, 0, s>>>(wgs, ws, d_out, n_waveguides, bufsize,
-                                                                  out_tracks);
+        gab::dwg_mix_kernel<<<(bufsize + 3) / 4, 256, 0, s>>>(wgs, ws, d_out, n_waveguides, bufsize,
+                                                              out_tracks);
         return gab::launch_status("dwg_mix_kernel");
     });
 }

@@ -58,11 +58,13 @@ def datatransfer(x, out_size):
     return out
 
 
-def iir(x, coeffs, state, tracks, bufsize):
-    """state (tracks*2, device) is updated in place."""
+def iir(x, coeffs, state, tracks, bufsize, sequential=False):
+    """state (tracks*2, device) is updated in place.  sequential=True forces the
+    lane-per-track kernel that is bit-identical to the golden."""
     out = torch.empty_like(x)
     c = (C.c_float * 5)(*[float(v) for v in coeffs])
-    check(lib.gab_iir(_dev(x), _dev(out), c, _dev(state), tracks, bufsize, _stream()))
+    fn = lib.gab_iir_sequential if sequential else lib.gab_iir
+    check(fn(_dev(x), _dev(out), c, _dev(state), tracks, bufsize, _stream()))
     return out
 
 

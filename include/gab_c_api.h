@@ -67,9 +67,17 @@ int gab_datatransfer(const float* d_in, float* d_out, int in_size, int out_size,
 
 /* IIRFilterKernel (cuda/bench_iir.cu:10-44): DF-II biquad per track,
  * coeffs = {b0,b1,b2,a1,a2} (HOST pointer, 5 floats), d_state = T x {z1,z2}
- * read and written back.  Same operation order as the golden: bit-exact.     */
+ * read and written back.
+ * gab_iir: one wavefront per track, wave-level scan of the state recurrence
+ * (bufsize in {64,128,256,512,1024}, 16-byte aligned buffers; other shapes take
+ * the sequential kernel).  Re-associates the recurrence: within ~1e-7 of the
+ * golden, not bit-identical.
+ * gab_iir_sequential: one lane per track in the golden's exact operation order,
+ * bit-identical to it.                                                        */
 int gab_iir(const float* d_in, float* d_out, const float* coeffs,
             float* d_state, int tracks, int bufsize, gab_stream_t stream);
+int gab_iir_sequential(const float* d_in, float* d_out, const float* coeffs,
+                       float* d_state, int tracks, int bufsize, gab_stream_t stream);
 
 /* Conv1DTextureMemoryImplKernel (cuda/bench_conv1d.cu:7-27) with the CPU
  * golden's semantics (:188-208): y[t*B+i] = sum_j h[t*L+j] * x_flat[t*B+i-j]

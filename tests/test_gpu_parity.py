@@ -98,20 +98,44 @@ def test_datatransfer(gab, orc, rin, rout):
 
 
 @pytest.mark.parametrize("T,B", [(128, 512), (5, 100), (200, 513)])
-def test_iir_bit_exact_with_carried_state(gab, orc, T, B):
+def test_iir_sequential_bit_exact_with_carried_state(gab, orc, T, B):
     c = orc.iir_coeffs(0.25)
     x = orc.noise(T * B)
     st_ref = np.zeros(2 * T, np.float32)
     st = dev(np.zeros(2 * T, np.float32))
     for it in range(3):                                   # state carries across buffers
         xi = np.roll(x, it * 17)
-        y = host(gab.iir(dev(xi), c, st, T, B))
+        y = host(gab.iir(dev(xi), c, st, T, B, sequential=True))
         ry = orc.iir(xi, c, st_ref, T, B)
         assert np.array_equal(bits(y), bits(ry)), "buffer %d" % it
         assert np.array_equal(bits(host(st)), bits(st_ref))
     if (T, B) == (128, 512):
         st0 = np.zeros(2 * T, np.float32)
         assert orc.fnv_survey(orc.iir(x, c, st0, T, B)) == "fad0d0724cb98566"
+
+
+@pytest.mark.parametrize("T,B", [(128, 512), (3, 64), (1000, 128), (7, 1024), (130, 256)])
+def test_iir_wave_scan_with_carried_state(gab, orc, T, B):
+    """The wave-scan kernel re-associates the recurrence: gated at 1e-5 of peak
+    (measured ~1e-7), outputs and carried state, over several buffers."""
+    c = orc.iir_coeffs(0.25)
+    x = orc.noise(T * B)
+    st_ref = np.zeros(2 * T, np.float32)
+    st = dev(np.zeros(2 * T, np.float32))
+    for it in range(4):
+        xi = np.roll(x, it * 29)
+        y = host(gab.iir(dev(xi), c, st, T, B))
+        ry = orc.iir(xi, c, st_ref, T, B)
+        assert peak_err(y, ry) <= TOL, (it, peak_err(y, ry))
+        assert peak_err(host(st), st_ref) <= TOL
+    # a different filter (narrow band-pass-like poles closer to the unit circle)
+    c2 = np.array([0.2, 0.1, -0.05, -1.2, 0.72], np.float32)
+    st_ref[:] = 0
+    st = dev(np.zeros(2 * T, np.float32))
+    for it in range(2):
+        y = host(gab.iir(dev(x), c2, st, T, B))
+        ry = orc.iir(x, c2, st_ref, T, B)
+        assert peak_err(y, ry) <= TOL
 
 
 @pytest.mark.parametrize("L,T,B", [(256, 256, 512), (1024, 16, 512), (100, 7, 300), (1500, 3, 64)])
