@@ -27,7 +27,9 @@
 // pressure grid, which is what a caller can read back, is unchanged).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <utility>
+#include <vector>
 
 #include "gab_common.hpp"
 
@@ -204,6 +206,18 @@ __global__ __launch_bounds__(256) void fdtd_step_vec4_kernel(Fields o, Fields n,
 }  // namespace
 }  // namespace gab
 
+// A buffer is hundreds to thousands of tiny dependent launches (3 per sample); at the
+// reference's 52^3 grid the kernel is shorter than the host's launch cost, so the
+// chain for one (input, output, range, ping-pong phase) signature is captured into a
+// hipGraph once and replayed.
+struct FdtdGraphKey {
+    const float* in; float* out; int tracks, bufsize, first, count; const float* cur_p;
+    bool operator==(const FdtdGraphKey& o) const {
+        return in == o.in && out == o.out && tracks == o.tracks && bufsize == o.bufsize &&
+               first == o.first && count == o.count && cur_p == o.cur_p;
+    }
+};
+
 struct gab_fdtd_plan {
     gab_fdtd_params P;
     gab::Fields cur{}, nxt{};          // ping-pong
@@ -211,6 +225,9 @@ struct gab_fdtd_plan {
     float* strip = nullptr;            // per-sample receiver values
     int strip_cap = 0;
     size_t np = 0, nvx = 0, nvy = 0, nvz = 0;
+    bool use_graphs = true;
+    hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
+    std::vector<std::pair<FdtdGraphKey, hipGraphExec_t>> graphs;   // small LRU, newest last
 };
 
 namespace {
@@ -271,6 +288,7 @@ int gab_fdtd_create(gab_fdtd_plan** out, const gab_fdtd_params* params) {
         if (P.steps_per_sample < 1) return gab::bad_arg("gab_fdtd_create: steps_per_sample must be >= 1");
         auto* f = new gab_fdtd_plan;
         f->P = P;
+        if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
         f->np = (size_t)P.nx * P.ny * P.nz;
         f->nvx = (size_t)(P.nx + 4) * P.ny * P.nz + 4;   // padded pitch, see file header
         f->nvy = (size_t)P.nx * (P.ny + 1) * P.nz;
@@ -293,6 +311,8 @@ int gab_fdtd_create(gab_fdtd_plan** out, const gab_fdtd_params* params) {
 int gab_fdtd_destroy(gab_fdtd_plan* f) {
     if (!f) return GAB_OK;
     (void)hipDeviceSynchronize();
+    for (auto& g : f->graphs) (void)hipGraphExecDestroy(g.second);
+    if (f->capture_stream) (void)hipStreamDestroy(f->capture_stream);
     free_fields(f->cur);
     free_fields(f->nxt);
     if (f->inj) (void)hipFree(f->inj);
@@ -323,6 +343,8 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         hipStream_t s = gab::as_stream(stream);
         if (f->strip_cap < bufsize) {
             GAB_HIP_CHECK(hipStreamSynchronize(s));
+            for (auto& c : f->graphs) (void)hipGraphExecDestroy(c.second);   // they point at the old strips
+            f->graphs.clear();
             if (f->inj) (void)hipFree(f->inj);
             if (f->strip) (void)hipFree(f->strip);
             f->inj = f->strip = nullptr;
@@ -337,36 +359,73 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         const float damp = 1.0f - P.absorption_coeff;
         const int last = first_sample + n_samples;
 
-        gab::fdtd_source_sums_kernel<<<(n_samples + 127) / 128, 128, 0, s>>>(d_in, f->inj, tracks, bufsize,
-                                                                           first_sample, n_samples);
-        // the first sample's source goes straight into the current pressure grid; later
-        // ones are folded into the step that precedes them
-        gab::fdtd_add_source_kernel<<<1, 64, 0, s>>>(f->cur.p, src, f->inj, first_sample);
-
-        const bool vec4 = (P.nx % 4) == 0;
-        const int tx = vec4 ? P.nx / 4 : P.nx;                    // threads along x
-        const int bx = tx >= 64 ? 64 : (tx >= 32 ? 32 : 16);
-        dim3 block(bx, 256 / bx, 1);
-        dim3 grid((tx + bx - 1) / bx, (P.ny + block.y - 1) / block.y, P.nz);
-        for (int smp = first_sample; smp < last; ++smp) {
-            for (int step = 0; step < P.steps_per_sample; ++step) {
-                const bool closes = step == P.steps_per_sample - 1;
-                const float* add_next = (closes && smp + 1 < last) ? f->inj + smp + 1 : nullptr;
-                float* strip_out = closes ? f->strip + smp : nullptr;
-                if (vec4)
-                    gab::fdtd_step_vec4_kernel<<<grid, block, 0, s>>>(f->cur, f->nxt, g, P.dt_over_rho_dx,
-                                                                     P.rho_c2_dt_over_dx, damp, src, rcv,
-                                                                     add_next, strip_out);
-                else
-                    gab::fdtd_step_kernel<<<grid, block, 0, s>>>(f->cur, f->nxt, g, P.dt_over_rho_dx,
-                                                                P.rho_c2_dt_over_dx, damp, src, rcv,
-                                                                add_next, strip_out);
-                std::swap(f->cur, f->nxt);
+        // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
+        auto enqueue = [&](hipStream_t q, gab::Fields cur, gab::Fields nxt) {
+            gab::fdtd_source_sums_kernel<<<(n_samples + 127) / 128, 128, 0, q>>>(d_in, f->inj, tracks, bufsize,
+                                                                               first_sample, n_samples);
+            // the first sample's source goes straight into the current pressure grid; later
+            // ones are folded into the step that precedes them
+            gab::fdtd_add_source_kernel<<<1, 64, 0, q>>>(cur.p, src, f->inj, first_sample);
+            const bool vec4 = (P.nx % 4) == 0;
+            const int tx = vec4 ? P.nx / 4 : P.nx;                    // threads along x
+            const int bx = tx >= 64 ? 64 : (tx >= 32 ? 32 : 16);
+            dim3 block(bx, 256 / bx, 1);
+            dim3 grid((tx + bx - 1) / bx, (P.ny + block.y - 1) / block.y, P.nz);
+            for (int smp = first_sample; smp < last; ++smp) {
+                for (int step = 0; step < P.steps_per_sample; ++step) {
+                    const bool closes = step == P.steps_per_sample - 1;
+                    const float* add_next = (closes && smp + 1 < last) ? f->inj + smp + 1 : nullptr;
+                    float* strip_out = closes ? f->strip + smp : nullptr;
+                    if (vec4)
+                        gab::fdtd_step_vec4_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx,
+                                                                         P.rho_c2_dt_over_dx, damp, src, rcv,
+                                                                         add_next, strip_out);
+                    else
+                        gab::fdtd_step_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx,
+                                                                    P.rho_c2_dt_over_dx, damp, src, rcv,
+                                                                    add_next, strip_out);
+                    std::swap(cur, nxt);
+                }
             }
+            dim3 bgrid((n_samples + 127) / 128, tracks);
+            gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
+                                                            n_samples);
+        };
+        const long launches = 3L + (long)n_samples * P.steps_per_sample;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        bool replayed = false;
+        if (f->use_graphs && launches >= 24 && cap == hipStreamCaptureStatusNone) {
+            const FdtdGraphKey key{d_in, d_out, tracks, bufsize, first_sample, n_samples, f->cur.p};
+            hipGraphExec_t exec = nullptr;
+            for (size_t i = 0; i < f->graphs.size(); ++i)
+                if (f->graphs[i].first == key) {
+                    auto hit = f->graphs[i];
+                    f->graphs.erase(f->graphs.begin() + i);
+                    f->graphs.push_back(hit);
+                    exec = hit.second;
+                    break;
+                }
+            if (!exec) {
+                hipGraph_t graph = nullptr;
+                if (!f->capture_stream)
+                    GAB_HIP_CHECK(hipStreamCreateWithFlags(&f->capture_stream, hipStreamNonBlocking));
+                GAB_HIP_CHECK(hipStreamBeginCapture(f->capture_stream, hipStreamCaptureModeThreadLocal));
+                enqueue(f->capture_stream, f->cur, f->nxt);
+                GAB_HIP_CHECK(hipStreamEndCapture(f->capture_stream, &graph));
+                GAB_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                if (f->graphs.size() >= 4) {
+                    (void)hipGraphExecDestroy(f->graphs.front().second);
+                    f->graphs.erase(f->graphs.begin());
+                }
+                f->graphs.emplace_back(key, exec);
+            }
+            GAB_HIP_CHECK(hipGraphLaunch(exec, s));
+            replayed = true;
         }
-        dim3 bgrid((n_samples + 127) / 128, tracks);
-        gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, s>>>(f->strip, d_out, tracks, bufsize, first_sample,
-                                                        n_samples);
+        if (!replayed) enqueue(s, f->cur, f->nxt);
+        if (((long)n_samples * P.steps_per_sample) & 1) std::swap(f->cur, f->nxt);
         return gab::launch_status("fdtd kernels");
     });
 }
