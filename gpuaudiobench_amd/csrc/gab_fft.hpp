@@ -63,6 +63,22 @@ __device__ __forceinline__ cf cfma(cf a, cf b, cf acc) {
         : "=&v"(r) : "v"(a), "v"(b), "v"(acc));
     return r;
 }
+// acc + conj(a)*b
+__device__ __forceinline__ cf cfma_cj(cf a, cf b, cf acc) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]\n\t"   // (+a.y*b.y, -a.y*b.x)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"                                      // (+a.x*b.x, +a.x*b.y)
+        : "=&v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
+}
+// acc + conj(a*b)
+__device__ __forceinline__ cf cfma_cjcj(cf a, cf b, cf acc) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"   // (-a.y*b.y, -a.y*b.x)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]"                                      // (+a.x*b.x, -a.x*b.y)
+        : "=&v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
+}
 // a * a
 __device__ __forceinline__ cf csqr(cf a) { return cmul(a, a); }
 
@@ -71,6 +87,27 @@ template <bool INV>
 __device__ __forceinline__ cf rot90(cf a) {
     return INV ? mk(-a.y, a.x) : mk(a.y, -a.x);
 }
+
+// a -/+ i*b in ONE packed add: op_sel swaps b's halves, neg_* flips one of them.
+// Written as rot90() + cadd() the compiler emits v_mov + v_xor + v_pk_add (a sixth
+// of this library's VALU instructions before these existed).
+// a - i*b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf addmi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + i*b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf addpi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + rot90<INV>(b)  and  a - rot90<INV>(b)
+template <bool INV>
+__device__ __forceinline__ cf add_rot(cf a, cf b) { return INV ? addpi(a, b) : addmi(a, b); }
+template <bool INV>
+__device__ __forceinline__ cf sub_rot(cf a, cf b) { return INV ? addmi(a, b) : addpi(a, b); }
 
 template <bool INV>
 __device__ __forceinline__ void bfly2(cf& a, cf& b) {
@@ -83,11 +120,23 @@ __device__ __forceinline__ void bfly2(cf& a, cf& b) {
 template <bool INV>
 __device__ __forceinline__ void bfly4(cf& a0, cf& a1, cf& a2, cf& a3) {
     cf t0 = cadd(a0, a2), t1 = csub(a0, a2);
-    cf t2 = cadd(a1, a3), t3 = rot90<INV>(csub(a1, a3));
+    cf t2 = cadd(a1, a3), d = csub(a1, a3);
     a0 = cadd(t0, t2);
-    a1 = cadd(t1, t3);
+    a1 = add_rot<INV>(t1, d);
     a2 = csub(t0, t2);
-    a3 = csub(t1, t3);
+    a3 = sub_rot<INV>(t1, d);
+}
+// The same with input 2 (ROT3: and input 3) still owed a factor -i (forward) / +i
+// (inverse): the rotation rides on the first layer's adds.
+template <bool INV, bool ROT3>
+__device__ __forceinline__ void bfly4_rot(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf t0 = add_rot<INV>(a0, a2), t1 = sub_rot<INV>(a0, a2);
+    cf t2 = ROT3 ? add_rot<INV>(a1, a3) : cadd(a1, a3);
+    cf d = ROT3 ? sub_rot<INV>(a1, a3) : csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a1 = add_rot<INV>(t1, d);
+    a2 = csub(t0, t2);
+    a3 = sub_rot<INV>(t1, d);
 }
 
 // multiply by W16^m (forward: exp(-2*pi*i*m/16); inverse: conjugate)
@@ -99,8 +148,8 @@ __device__ __forceinline__ cf tw16(cf a) {
     if constexpr (M == 0) return a;
     else if constexpr (M == 4) return rot90<INV>(a);
     else if constexpr (M == 2) {
-        // (x+iy)(H -/+ iH)
-        return INV ? mk((a.x - a.y) * H, (a.x + a.y) * H) : mk((a.x + a.y) * H, (a.y - a.x) * H);
+        // (x+iy)(H -/+ iH): two packed instructions
+        return INV ? cmulc(a, mk(H, -H)) : cmul(a, mk(H, -H));
     } else if constexpr (M == 6) {
         // (x+iy)(-H -/+ iH)
         return INV ? mk(-(a.x + a.y) * H, (a.x - a.y) * H) : mk((a.y - a.x) * H, -(a.x + a.y) * H);
@@ -158,16 +207,16 @@ struct Butterfly<16, INV> {
         v[5] = tw16<INV, 1>(v[5]);
         v[6] = tw16<INV, 2>(v[6]);
         v[7] = tw16<INV, 3>(v[7]);
+        // W^4 = -/+i and W^6 = -/+i * W^2: the quarter turns are folded into the next layer
         v[9] = tw16<INV, 2>(v[9]);
-        v[10] = tw16<INV, 4>(v[10]);
-        v[11] = tw16<INV, 6>(v[11]);
+        v[11] = tw16<INV, 2>(v[11]);
         v[13] = tw16<INV, 3>(v[13]);
-        v[14] = tw16<INV, 6>(v[14]);
+        v[14] = tw16<INV, 2>(v[14]);
         v[15] = tw16<INV, 9>(v[15]);
         bfly4<INV>(v[0], v[1], v[2], v[3]);
         bfly4<INV>(v[4], v[5], v[6], v[7]);
-        bfly4<INV>(v[8], v[9], v[10], v[11]);
-        bfly4<INV>(v[12], v[13], v[14], v[15]);
+        bfly4_rot<INV, true>(v[8], v[9], v[10], v[11]);
+        bfly4_rot<INV, false>(v[12], v[13], v[14], v[15]);
     }
     // X[k1 + 4*k2] is in v[4*k1 + k2]
     __host__ __device__ static constexpr int out_slot(int k) { return 4 * (k & 3) + (k >> 2); }
@@ -179,14 +228,15 @@ struct Butterfly<16, INV> {
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) {
             cf t0 = cadd(v[n2], v[8 + n2]), t1 = csub(v[n2], v[8 + n2]);
-            cf t2 = cadd(v[4 + n2], v[12 + n2]), t3 = rot90<INV>(csub(v[4 + n2], v[12 + n2]));
+            cf t2 = cadd(v[4 + n2], v[12 + n2]), d = csub(v[4 + n2], v[12 + n2]);
             y2[n2] = csub(t0, t2);
-            y3[n2] = csub(t1, t3);
+            y3[n2] = sub_rot<INV>(t1, d);
         }
-        y2[1] = tw16<INV, 2>(y2[1]); y2[2] = tw16<INV, 4>(y2[2]); y2[3] = tw16<INV, 6>(y2[3]);
-        y3[1] = tw16<INV, 3>(y3[1]); y3[2] = tw16<INV, 6>(y3[2]); y3[3] = tw16<INV, 9>(y3[3]);
-        x14 = csub(csub(y2[0], y2[2]), rot90<INV>(csub(y2[1], y2[3])));
-        x15 = csub(csub(y3[0], y3[2]), rot90<INV>(csub(y3[1], y3[3])));
+        // twiddles W^(2 n2) and W^(3 n2); the quarter turns of W^4, W^6 ride on the adds below
+        y2[1] = tw16<INV, 2>(y2[1]); y2[3] = tw16<INV, 2>(y2[3]);            // y2[2], y2[3] owe a rot90
+        y3[1] = tw16<INV, 3>(y3[1]); y3[2] = tw16<INV, 2>(y3[2]); y3[3] = tw16<INV, 9>(y3[3]);   // y3[2] owes one
+        x14 = sub_rot<INV>(sub_rot<INV>(y2[0], y2[2]), sub_rot<INV>(y2[1], y2[3]));
+        x15 = sub_rot<INV>(sub_rot<INV>(y3[0], y3[2]), csub(y3[1], y3[3]));
     }
 };
 
@@ -224,6 +274,15 @@ struct TwiddleSet {
 template <int PASSES>
 struct TwiddleBases {
     cf w[PASSES > 1 ? PASSES - 1 : 1];
+};
+
+// In between: all powers of the LAST pass, only the base of the earlier ones (which are
+// re-formed inside each pass).  Saves (PASSES-2)*(R-2) complex registers for R-2
+// products per earlier pass and direction.
+template <int R, int PASSES>
+struct TwiddleMixed {
+    cf base[PASSES > 2 ? PASSES - 2 : 1];
+    cf last[R - 1];
 };
 
 template <int R>
@@ -280,6 +339,28 @@ struct BlockFFT {
         powers_of<R>(b, w);
     }
 
+    using Mixed = TwiddleMixed<R, PASSES>;
+    __device__ static __forceinline__ void pass_twiddles(const Mixed& t, int p, cf (&w)[R - 1]) {
+        if (p == PASSES - 1) {
+#pragma unroll
+            for (int r = 0; r < R - 1; ++r) w[r] = t.last[r];
+        } else {
+            cf b = t.base[p - 1];
+            asm volatile("" : "+v"(b.x), "+v"(b.y));
+            powers_of<R>(b, w);
+        }
+    }
+    __device__ static __forceinline__ void load_twiddles(Mixed& t, const cf* __restrict__ tw, int tid) {
+        cf lastb;
+#pragma unroll
+        for (int p = 1; p < PASSES; ++p) {
+            const int Ns = ipow(R, p);
+            cf b = tw[(tid & (Ns - 1)) * (kTwiddleN / (Ns * R))];
+            if (p == PASSES - 1) lastb = b; else t.base[p - 1] = b;
+        }
+        powers_of<R>(lastb, t.last);
+    }
+
     __device__ static __forceinline__ void load_twiddles(Twiddles& t, const cf* __restrict__ tw, int tid) {
         cf base[PASSES];
 #pragma unroll
@@ -291,14 +372,26 @@ struct BlockFFT {
         for (int p = 1; p < PASSES; ++p) powers_of<R>(base[p], t.w[p - 1]);
     }
 
+    // bases -> all powers, for callers that fetch the bases early but cannot afford the
+    // (PASSES-1)*(R-1) registers until later
+    __device__ static __forceinline__ void expand_twiddles(const Bases& b, Twiddles& t) {
+#pragma unroll
+        for (int p = 1; p < PASSES; ++p) powers_of<R>(b.w[p - 1], t.w[p - 1]);
+    }
+
     // `active` lets a workgroup wider than NT threads run the transform on its first
     // NT threads: the others skip the arithmetic but still meet every barrier.
     // LAST2 (radix 16 only): the caller needs just X[tid + 14*NT] and X[tid + 15*NT];
     // they are returned in v[14], v[15], every other v[] is then unspecified.
-    template <class TW, bool LAST2 = false>
+    // `hook(p)` runs right after the barrier that closes pass p (p < PASSES-1): a place
+    // for the caller to slip independent work (e.g. a couple of global loads) into the
+    // transform's instruction stream.
+    struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+    template <class TW, bool LAST2 = false, class Hook = NoHook>
     __device__ static __forceinline__ void run(cf (&v)[R], cf* __restrict__ ldsA,
                                                cf* __restrict__ ldsB, const TW& tws, int tid,
-                                               bool active = true) {
+                                               bool active = true, Hook hook = Hook()) {
         // Opaque copy: stops the compiler from sharing LDS address arithmetic between
         // separate transforms of one kernel, which it otherwise keeps live (and spills)
         // across everything in between.
@@ -358,6 +451,7 @@ struct BlockFFT {
                     }
                 }
                 __syncthreads();
+                hook(p);
             } else if (active) {
                 // leave X[tid + r*NT] in v[r]
                 cf o[R];

@@ -87,7 +87,7 @@ constexpr int kLdsHalf = PadB::size(kNB);       // cf entries per LDS buffer
 
 // Partner exchange: every thread publishes its R bins (k = tid + r*N/R) and
 // fetches conj(Z[(N-k) mod N]).  Threads beyond N/R only meet the barrier.
-template <int N, int R>
+template <int N, int R, bool RAW = false>
 __device__ __forceinline__ void partner_exchange(const cf (&z)[R], cf (&zp)[R],
                                                  cf* __restrict__ lds, int tid, bool active = true) {
     constexpr int NT = N / R;
@@ -100,7 +100,8 @@ __device__ __forceinline__ void partner_exchange(const cf (&z)[R], cf (&zp)[R],
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int k = tid + r * NT;
-            zp[r] = fft::conj(lds[(N - k) & (N - 1)]);
+            cf v = lds[(N - k) & (N - 1)];
+            zp[r] = RAW ? v : fft::conj(v);      // RAW: the caller folds the conjugate into its product
         }
     }
 }
@@ -122,18 +123,17 @@ __device__ __forceinline__ void load_spectra(float4 (&c)[R], const float4* __res
     }
 }
 
-// W[k] = Z[k]*P[k] + Z'[k]*M[k]
+// W[k] = Z[k]*P[k] + Z'[k]*M[k], Z' = conj(zraw) (zraw = Z[N-k] as fetched, unconjugated)
 template <int N, int R>
-__device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zp)[R], const float4 (&c)[R],
+__device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zraw)[R], const float4 (&c)[R],
                                                  int tid) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         cf P = mk(c[r].x, c[r].y), M = mk(c[r].z, c[r].w);
-        if (r > R / 2 || (r == R / 2 && tid != 0)) {       // conjugate half
-            // z*conj(P) + zp*conj(M)
-            z[r] = fft::cadd(fft::cmulc(z[r], P), fft::cmulc(zp[r], M));
+        if (r > R / 2 || (r == R / 2 && tid != 0)) {       // conjugate half: z*conj(P) + conj(zraw*M)
+            z[r] = fft::cfma_cjcj(zraw[r], M, fft::cmulc(z[r], P));
         } else {
-            z[r] = fft::cfma(zp[r], M, fft::cmul(z[r], P));
+            z[r] = fft::cfma_cj(zraw[r], M, fft::cmul(z[r], P));
         }
     }
 }
@@ -150,17 +150,18 @@ __device__ __forceinline__ void keep_alive(const T& v) {
 // ABL == 6: lane 0 of every workgroup records s_memrealtime (100 MHz) at phase
 // boundaries into a buffer nothing else reads.
 __device__ unsigned long long g_conv_stamps[8 * 4096];
-#define GAB_STAMP(i)                                                                   \
+#define GAB_STAMP_T(i, t)                                                              \
     do {                                                                               \
-        if constexpr (ABL == 6) {                                                      \
+        if constexpr (ABL == 6 || ABL == 7) {                                          \
             __builtin_amdgcn_sched_barrier(0);                                         \
-            if (threadIdx.x == 0) g_conv_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+            if (threadIdx.x == (t)) g_conv_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
             __builtin_amdgcn_sched_barrier(0);                                         \
         }                                                                              \
     } while (0)
 #else
-#define GAB_STAMP(i) do {} while (0)
+#define GAB_STAMP_T(i, t) do {} while (0)
 #endif
+#define GAB_STAMP(i) GAB_STAMP_T(i, 0)
 
 // (Tried and measured slower, so not kept: running partition B first in half of
 // the workgroups to de-phase the two workgroups that share a CU, 14.8 vs 14.0 us;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     cf za[4];
     float4 ca[4];
     typename FA::Twiddles twa;      // all powers precomputed while the first loads are in flight
-    typename FB::Twiddles twb;
+    typename FB::Bases twb_base;    // partition B's are expanded after A (60 registers)
 
     // ---- requests, in need order: partition A's inputs (new block, previous block,
     // its spectra) first, then the older history partition B works on, so A's
@@ -212,31 +213,54 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
         za[0] = mk(0.0f, 0.0f);
         za[1] = mk(0.0f, 0.0f);
     }
+    __builtin_amdgcn_sched_barrier(0);      // keep the request order: a wave's loads return in order
     load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
-    FA::load_twiddles(twa, tw, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    typename FA::Bases twa_base;
+    FA::load_twiddles(twa_base, tw, tid);
     if constexpr (STREAM && TAIL) {
-        FB::load_twiddles(twb, tw, tid);
+        FB::load_twiddles(twb_base, tw, tid);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 14; ++r)
             zb[r] = hp[((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid];
         zb[14] = za[0];
         zb[15] = za[1];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    FA::expand_twiddles(twa_base, twa);      // while the first loads are in flight
     if constexpr (STREAM) {
         // overwrite the oldest block (already requested into zb[0..1]) with the new one
         hp[head * kB + tid] = za[2];
         hp[head * kB + kThreads + tid] = za[3];
     }
     GAB_STAMP(1);
+#ifdef GAB_ABLATE
+    if constexpr (ABL == 6) {
+        if (threadIdx.x == 0) {
+            g_conv_stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+            g_conv_stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+        }
+    }
+#endif
+    // Two of these workgroups share a CU and the one dispatched second (blockIdx + grid/2
+    // on a 512-workgroup grid) gets its first data ~1 us later and then loses most issue
+    // arbitration to the older waves: it finished 2.6 us after its neighbour.  Raising its
+    // priority evens the pair out (11.8 -> 11.55 us per launch); delaying either one by any
+    // amount only cost time.
+    if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
 
     // ---- stages.  LDS hand-over is barrier-free by construction: a stage called
     // with (X, Y) first writes X and makes its last reads from X, so the next
     // stage is called with (Y, X) — Y's last readers are behind a barrier by then.
     float ya0 = 0.f, yb0 = 0.f, ya1 = 0.f, yb1 = 0.f;
+    // (Partition B's spectra are requested when B starts.  Asked for up front they queue
+    // in the CU's request path ahead of other waves' FIRST loads: first data +1 us, 14.0 us
+    // per launch; trickled out two loads per pass of A: 12.1 us; at B's start: 11.8 us.)
     auto part_a = [&](cf* X, cf* Y) {
         FA::run(za, X, Y, twa, tid);                         // 5 passes: last reads Y
         cf zpa[4];
-        partner_exchange<kNA, 4>(za, zpa, X, tid);
+        partner_exchange<kNA, 4, true>(za, zpa, X, tid);
         spectral_product<kNA, 4>(za, zpa, ca, tid);
         FAi::run(za, Y, X, twa, tid);                        // last reads X
         ya0 += za[2].x; yb0 += za[2].y;
@@ -249,19 +273,42 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
             float4 cb[16];
             load_spectra<kNB, 16>(cb, pmB + (size_t)q * kBinsB, tid);
             __builtin_amdgcn_sched_barrier(0);
+            typename FB::Twiddles twb;
+            FB::expand_twiddles(twb_base, twb);
             FB::run(zb, X, Y, twb, tid);                     // 3 passes: last reads Y
             cf zpb[16];
-            partner_exchange<kNB, 16>(zb, zpb, X, tid);
+            partner_exchange<kNB, 16, true>(zb, zpb, X, tid);
             spectral_product<kNB, 16>(zb, zpb, cb, tid);
             FBi::template run<typename FB::Twiddles, true>(zb, Y, X, twb, tid);   // last reads X; only [14],[15]
             ya0 += zb[14].x; yb0 += zb[14].y;
             ya1 += zb[15].x; yb1 += zb[15].y;
         }
     };
+#ifdef GAB_ABLATE
+    if constexpr (ABL == 7) {
+        // I-cache experiment: the same code three times; slots 2,3,4 = A done x3, then B x2 in 5,6
+        for (int i = 0; i < 3; ++i) {
+            part_a(lds0, lds1);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (threadIdx.x == 0) g_conv_stamps[blockIdx.x * 8 + 2 + i] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int i = 0; i < 2; ++i) {
+            part_b(lds1, lds0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (threadIdx.x == 0) g_conv_stamps[blockIdx.x * 8 + 5 + i] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
+#endif
+    {
     part_a(lds0, lds1);
     GAB_STAMP(2);
     part_b(lds1, lds0);
     GAB_STAMP(6);
+    }
 
     // ---- scatter: sample-major out[T*s + t], s = tid and tid+256 -----------
     float* o0 = out + (size_t)T * tid + ta;
@@ -532,6 +579,8 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
 #ifdef GAB_ABLATE
             else if (getenv("GAB_CONV_ABLATE") && atoi(getenv("GAB_CONV_ABLATE")) == 6)
                 gab::conv_overlap_save_kernel<true, true, 6><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
+            else if (getenv("GAB_CONV_ABLATE") && atoi(getenv("GAB_CONV_ABLATE")) == 7)
+                gab::conv_overlap_save_kernel<true, true, 7><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
 #endif
             else
                 gab::conv_overlap_save_kernel<true, true><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
