@@ -464,6 +464,76 @@ struct BlockFFT {
     }
 };
 
+// A 1024-point transform held by ONE wave: 64 lanes x 16 values, lane j enters with
+// v[r] = x[j + 64 r] and leaves with v[r] = X[j + 64 r].  Passes: four radix-4
+// butterflies per lane (Ns = 1), radix-16 (Ns = 4), radix-16 (Ns = 64).  The two
+// exchanges go through a wave-private LDS image of Pad<16>::size(1024) entries and
+// need no workgroup barrier: a wave's LDS instructions execute in order.
+struct Wave1024Twiddles {
+    cf w1;         // W64^(j&3): its powers are re-formed in the pass (registers)
+    cf w2[15];     // W1024^(j i), i = 1..15
+};
+
+template <bool INV>
+struct WaveFFT1024 {
+    static constexpr int N = 1024;
+    using P = Pad<16>;
+    using Twiddles = Wave1024Twiddles;
+
+    __device__ static __forceinline__ void load_twiddles(Twiddles& t, const cf* __restrict__ tw, int lane) {
+        t.w1 = tw[(lane & 3) * (kTwiddleN / 64)];
+        powers_of<16>(tw[lane * (kTwiddleN / 1024)], t.w2);
+    }
+
+    __device__ static __forceinline__ void run(cf (&v)[16], cf* __restrict__ img, const Twiddles& t,
+                                               int lane_in) {
+        unsigned lane = (unsigned)lane_in;
+        asm volatile("" : "+v"(lane));
+        // pass 0: butterflies b = lane + 64 m on v[m + 4 i]; y[4 b + i]
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bfly4<INV>(v[m], v[m + 4], v[m + 8], v[m + 12]);
+        {
+            // Pad(4 lane + 256 m + i) = 4 lane + (lane >> 2) + 272 m + i
+            const unsigned wb = 4u * lane + (lane >> 2);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) img[wb + 272 * m + i] = v[m + 4 * i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned rb = lane + (lane >> 4);         // Pad(lane + 64 r) = rb + 68 r
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = img[rb + 68 * r];
+        {
+            cf b = t.w1, w1[15];
+            asm volatile("" : "+v"(b.x), "+v"(b.y));
+            powers_of<16>(b, w1);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v[r] = INV ? cmulc(v[r], w1[r - 1]) : cmul(v[r], w1[r - 1]);
+        }
+        Butterfly<16, INV>::run(v);
+        __builtin_amdgcn_wave_barrier();
+        {
+            // y[(lane/4) 64 + (lane&3) + 4 k]; Pad = (lane>>2) 68 + (lane&3) + 4 k + (k >> 2)
+            const unsigned wb = (lane >> 2) * 68u + (lane & 3u);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) img[wb + 4 * k + (k >> 2)] = v[Butterfly<16, INV>::out_slot(k)];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = img[rb + 68 * r];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = INV ? cmulc(v[r], t.w2[r - 1]) : cmul(v[r], t.w2[r - 1]);
+        Butterfly<16, INV>::run(v);
+        __builtin_amdgcn_wave_barrier();
+        cf o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = v[Butterfly<16, INV>::out_slot(k)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = o[k];
+    }
+};
+
 // Host: fill the float64-accurate twiddle table (kTwiddleN complex floats).
 void build_twiddles(float* table_xy);
 

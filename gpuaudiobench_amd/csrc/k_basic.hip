@@ -135,23 +135,32 @@ __global__ __launch_bounds__(kBlock) void modal_placeholder_kernel(const float* 
 // ---- rndmem -----------------------------------------------------------------------
 // 64x64 tile: rows = tracks read along the sample axis (256 B per wave load,
 // arbitrary 4-byte alignment since playheads are random), transposed through
-// LDS, written with tracks along the lanes: out[T*i + t].
+// LDS, written with tracks along the lanes: out[T*i + t].  A wave's 16 rows are
+// requested back to back (their playheads are wave-uniform scalar loads), so a
+// workgroup pays the pool's miss latency once, not once per batch of four.
 __global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict__ pool,
                                                        const int* __restrict__ playheads,
                                                        float* __restrict__ out, int T, int B) {
     __shared__ float tile[64][65];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
-#pragma unroll 4
-    for (int r = w; r < 64; r += 4) {
-        int t = t0 + r, i = i0 + lane;
-        if (t < T && i < B) tile[r][lane] = pool[(size_t)playheads[t] + i];
+    const bool col_ok = i0 + lane < B;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = t0 + w + 4 * k;                      // wave-uniform
+        const size_t ph = t < T ? (size_t)playheads[t] : 0;
+        v[k] = (t < T && col_ok) ? pool[ph + i0 + lane] : 0.0f;
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile[w + 4 * k][lane] = v[k];
     __syncthreads();
-#pragma unroll 4
-    for (int r = w; r < 64; r += 4) {
-        int i = i0 + r, t = t0 + lane;
-        if (t < T && i < B) out[(size_t)T * i + t] = tile[lane][r];
+    const int t = t0 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = i0 + w + 4 * k;
+        if (t < T && i < B) out[(size_t)T * i + t] = tile[lane][w + 4 * k];
     }
 }
 

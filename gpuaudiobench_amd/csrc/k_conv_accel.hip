@@ -386,32 +386,42 @@ __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
     }
 }
 
-// Batched 1024-point R2C (cuda/bench_fft.cu:63,105): two tracks per transform.
+// Batched 1024-point R2C (cuda/bench_fft.cu:63,105): two tracks per complex transform,
+// one transform per WAVE (64 lanes x 16 values, three passes, exchanges private to the
+// wave: no workgroup barrier anywhere), four waves per workgroup.
+using PadA16 = fft::Pad<16>;
+constexpr int kWaveImg = PadA16::size(kNA);
+
 __global__ __launch_bounds__(kThreads) void fft_r2c_1024_kernel(
     const float* __restrict__ in, float2* __restrict__ out, const cf* __restrict__ tw, int T) {
-    using PadA = fft::Pad<4>;
-    __shared__ cf lds[2 * PadA::size(kNA)];
-    cf* const lds0 = lds;
-    cf* const lds1 = lds + PadA::size(kNA);
-    const int tid = threadIdx.x;
-    const int q = blockIdx.x;
+    __shared__ cf lds[4 * kWaveImg];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cf* const img = lds + w * kWaveImg;
+    const int q = blockIdx.x * 4 + w;
     const int ta = 2 * q, tb = 2 * q + 1;
+    if (ta >= T) return;                                   // whole wave; no barriers below
     const bool hasb = tb < T;
     const float* xa = in + (size_t)ta * kNA;
     const float* xb = in + (size_t)tb * kNA;
-    cf z[4], zp[4];
+    cf z[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        z[r] = mk(xa[tid + r * kThreads], hasb ? xb[tid + r * kThreads] : 0.0f);
-    fft::BlockFFT<kNA, 4, false>::Twiddles t;
-    fft::BlockFFT<kNA, 4, false>::load_twiddles(t, tw, tid);
-    fft::BlockFFT<kNA, 4, false>::run(z, lds0, lds1, t, tid);
-    partner_exchange<kNA, 4>(z, zp, lds0, tid);
+    for (int r = 0; r < 16; ++r) z[r] = mk(xa[lane + 64 * r], hasb ? xb[lane + 64 * r] : 0.0f);
+    using WF = fft::WaveFFT1024<false>;
+    WF::Twiddles t;
+    WF::load_twiddles(t, tw, lane);
+    WF::run(z, img, t, lane);
+    // partner Z[(N - k) mod N], k = lane + 64 r: bins 0..512 are r < 8 plus (r = 8, lane 0)
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int k = tid + r * kThreads;
+    for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int k = lane + 64 * r;
         if (k <= kNA / 2) {
-            cf s = fft::cadd(z[r], zp[r]), d = fft::csub(z[r], zp[r]);
+            const cf zp = fft::conj(img[PadA16::at((kNA - k) & (kNA - 1))]);
+            const cf s = fft::cadd(z[r], zp), d = fft::csub(z[r], zp);
             out[(size_t)ta * kBinsA + k] = make_float2(0.5f * s.x, 0.5f * s.y);
             if (hasb) out[(size_t)tb * kBinsA + k] = make_float2(0.5f * d.y, -0.5f * d.x);
         }
@@ -628,7 +638,7 @@ int gab_fft_r2c_1024(const float* d_in, float* d_out, int tracks, gab_stream_t s
         if (!d_in || !d_out) return gab::bad_arg("gab_fft_r2c_1024: null pointer");
         if (tracks <= 0) return gab::bad_arg("gab_fft_r2c_1024: tracks must be > 0");
         const gab::fft::cf* tw = gab::fft::device_twiddles();
-        gab::fft_r2c_1024_kernel<<<(tracks + 1) / 2, gab::kThreads, 0, gab::as_stream(stream)>>>(
+        gab::fft_r2c_1024_kernel<<<(tracks + 7) / 8, gab::kThreads, 0, gab::as_stream(stream)>>>(
             d_in, reinterpret_cast<float2*>(d_out), tw, tracks);
         return gab::launch_status("fft_r2c_1024_kernel");
     });
