@@ -113,6 +113,12 @@ PROTOTYPES = {
     "gab_bench_latencies": (_I, [_P, C.POINTER(_F), _I]),
     "gab_bench_validation_text": (C.c_char_p, [_P]),
     "gab_bench_algorithmic_bytes": (_I, [_P, C.POINTER(_Z)]),
+    "gab_dawsim_create": (_I, [C.POINTER(_P), C.c_double, _I, C.c_double]),
+    "gab_dawsim_wait": (_I, [_P]),
+    "gab_dawsim_stats": (_I, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "gab_dawsim_destroy": (_I, [_P]),
+    "gab_bench_set_dawsim": (_I, [_P, _I, C.c_double, _I, C.c_double]),
+    "gab_bench_dawsim_stats": (_I, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 
 

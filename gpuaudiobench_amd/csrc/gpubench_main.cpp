@@ -33,6 +33,9 @@ void printHelp() {
     printf("  --irLength [taps]   Impulse-response length for Conv1D / Conv1D_accel\n");
     printf("  --fdtdGrid [n]      FDTD3D grid edge including the boundary shell (default: 52)\n");
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
+    printf("  --dawsim            Pace iterations to one buffer slot each (bufferSize / fs)\n");
+    printf("  --dawsim-mode [m]   spin | sleep (default: spin)\n");
+    printf("  --dawsim-jitter-us [us]  Uniform jitter on each slot (default: 0)\n");
     printf("\nAvailable Benchmarks:\n=====================\n");
     printf("\nData Transfer:\n");
     printf("  datacopy0199     - 1%% input, 99%% output transfer\n");
@@ -62,10 +65,25 @@ void printHelp() {
     printf("  gpubench --benchmark FDTD3D --fdtdGrid 128 --nRuns 5\n\n");
 }
 
+// --dawsim flags (metal-swift/MetalSwiftBench/main.swift:110-133)
+static bool g_dawsim = false;
+static BenchmarkUtils::DAWSimulationMode g_dawsim_mode = BenchmarkUtils::DAWSimulationMode::SPIN;
+static double g_dawsim_jitter_us = 0.0;
+
 void runSelectedBenchmark(std::unique_ptr<GPUABenchmark> benchmark, const std::string& name) {
     try {
         printf("Setting up %s benchmark...\n", name.c_str());
         benchmark->setupBenchmark();
+        if (g_dawsim) {
+            BenchmarkUtils::DAWSimulator sim;
+            sim.bufferDuration = (double)BUFSIZE / (double)FS;
+            sim.mode = g_dawsim_mode;
+            sim.jitterSeconds = g_dawsim_jitter_us * 1e-6;
+            benchmark->setDawSimulator(sim);
+            printf("DAW simulation: %s, buffer slot %.3f ms, jitter +/-%.1f us\n",
+                   g_dawsim_mode == BenchmarkUtils::DAWSimulationMode::SPIN ? "spin" : "sleep",
+                   sim.bufferDuration * 1e3, g_dawsim_jitter_us);
+        }
         printf("Running %s benchmark (%d iterations with %d warmup)...\n", name.c_str(), NRUNS, 3);
         auto result = benchmark->runBenchmark(NRUNS, 3);
 
@@ -90,6 +108,9 @@ void runSelectedBenchmark(std::unique_ptr<GPUABenchmark> benchmark, const std::s
                 printf("Roofline: %.0f algorithmic bytes / %.3f ms device time = %.1f GB/s (%.1f%% of 8 TB/s)\n",
                        bytes, result.gpu_statistics.median, gbs, 100.0 * gbs / 8000.0);
             }
+            if (g_dawsim)
+                printf("DAW simulation: %llu slots, %llu missed (iteration longer than %.3f ms)\n",
+                       result.daw_waits, result.daw_missed_slots, 1e3 * (double)BUFSIZE / (double)FS);
         }
         printf("%s benchmark completed successfully!\n", name.c_str());
     } catch (const std::exception& e) {
@@ -132,6 +153,18 @@ int main(int argc, char** argv) {
         else if (strcmp(argv[i], "--convMode") == 0) {
             if (!need("--convMode")) return 1;
             CONV_STREAMING = strcmp(argv[++i], "stateless") == 0 ? 0 : 1;
+        } else if (strcmp(argv[i], "--dawsim") == 0) {
+            g_dawsim = true;
+        } else if (strcmp(argv[i], "--dawsim-mode") == 0) {
+            if (!need("--dawsim-mode")) return 1;
+            const char* m = argv[++i];
+            if (strcmp(m, "spin") == 0) g_dawsim_mode = BenchmarkUtils::DAWSimulationMode::SPIN;
+            else if (strcmp(m, "sleep") == 0) g_dawsim_mode = BenchmarkUtils::DAWSimulationMode::SLEEP;
+            else { printf("Error: Unknown DAW simulation mode '%s'. Expected spin | sleep.\n", m); return 1; }
+        } else if (strcmp(argv[i], "--dawsim-jitter-us") == 0) {
+            if (!need("--dawsim-jitter-us")) return 1;
+            g_dawsim_jitter_us = atof(argv[++i]);
+            if (g_dawsim_jitter_us < 0.0) { printf("Error: --dawsim-jitter-us must be >= 0\n"); return 1; }
         } else {
             printf("Warning: Unparsed argument: %s\n", argv[i]);
         }

@@ -78,6 +78,7 @@ GPUABenchmark::BenchmarkResult GPUABenchmark::runWithIteration(int iterations, i
     result.track_count = track_count_;
     result.iterations = iterations;
 
+    BenchmarkUtils::DAWSimulationState daw_state;
     if (warmupIterations > 0) {
         if (!GAB_QUIET) printf("Running %d warmup iterations...\n", warmupIterations);
         for (int i = 0; i < warmupIterations; ++i) {
@@ -89,6 +90,7 @@ GPUABenchmark::BenchmarkResult GPUABenchmark::runWithIteration(int iterations, i
                 // a failing warm-up is reported and skipped, as in the reference
                 printf("  Warmup iteration %d failed: %s\n", i + 1, e.what());
             }
+            if (daw_enabled_) daw_simulator_.wait(daw_state);
         }
         if (!GAB_QUIET) printf("Warmup complete, starting timed iterations...\n");
     }
@@ -101,7 +103,10 @@ GPUABenchmark::BenchmarkResult GPUABenchmark::runWithIteration(int iterations, i
         double ms = BenchmarkUtils::BenchmarkTimer::measureKernel(body);
         result.latencies.push_back(static_cast<float>(ms));
         gpu.push_back(current_iteration_gpu_ms_);
+        if (daw_enabled_) daw_simulator_.wait(daw_state);
     }
+    result.daw_waits = daw_state.waits;
+    result.daw_missed_slots = daw_state.late;
     result.statistics = BenchmarkUtils::calculateStatistics(result.latencies);
 
     const bool any_gpu = std::any_of(gpu.begin(), gpu.end(), [](float v) { return v > 0.0f; });

@@ -208,4 +208,67 @@ int gab_bench_latencies(gab_bench* b, float* out, int capacity) {
     return n;
 }
 
+struct gab_dawsim {
+    BenchmarkUtils::DAWSimulator sim;
+    BenchmarkUtils::DAWSimulationState state;
+};
+
+static int dawsim_fill(BenchmarkUtils::DAWSimulator& sim, double buffer_seconds, int mode, double jitter_seconds,
+                       const char* who) {
+    if (!(buffer_seconds > 0.0) || jitter_seconds < 0.0 || (mode != 0 && mode != 1)) {
+        std::string m = std::string(who) + ": buffer_seconds must be > 0, jitter_seconds >= 0, mode 0 (spin) or 1 (sleep)";
+        return gab::bad_arg(m.c_str());
+    }
+    sim.bufferDuration = buffer_seconds;
+    sim.mode = mode == 1 ? BenchmarkUtils::DAWSimulationMode::SLEEP : BenchmarkUtils::DAWSimulationMode::SPIN;
+    sim.jitterSeconds = jitter_seconds;
+    return GAB_OK;
+}
+
+int gab_dawsim_create(gab_dawsim** s, double buffer_seconds, int mode, double jitter_seconds) {
+    return gab::guarded([&]() -> int {
+        if (!s) return gab::bad_arg("gab_dawsim_create: null handle pointer");
+        BenchmarkUtils::DAWSimulator sim;
+        if (int rc = dawsim_fill(sim, buffer_seconds, mode, jitter_seconds, "gab_dawsim_create")) return rc;
+        *s = new gab_dawsim{sim, {}};
+        return GAB_OK;
+    });
+}
+
+int gab_dawsim_wait(gab_dawsim* s) {
+    if (!s) return gab::bad_arg("gab_dawsim_wait: null handle");
+    s->sim.wait(s->state);
+    return GAB_OK;
+}
+
+int gab_dawsim_stats(const gab_dawsim* s, unsigned long long* waits, unsigned long long* missed_slots) {
+    if (!s) return gab::bad_arg("gab_dawsim_stats: null handle");
+    if (waits) *waits = s->state.waits;
+    if (missed_slots) *missed_slots = s->state.late;
+    return GAB_OK;
+}
+
+int gab_dawsim_destroy(gab_dawsim* s) {
+    delete s;
+    return GAB_OK;
+}
+
+int gab_bench_set_dawsim(gab_bench* b, int enable, double buffer_seconds, int mode, double jitter_seconds) {
+    return gab::guarded([&]() -> int {
+        if (!b) return gab::bad_arg("gab_bench_set_dawsim: null benchmark");
+        if (!enable) { b->impl->clearDawSimulator(); return GAB_OK; }
+        BenchmarkUtils::DAWSimulator sim;
+        if (int rc = dawsim_fill(sim, buffer_seconds, mode, jitter_seconds, "gab_bench_set_dawsim")) return rc;
+        b->impl->setDawSimulator(sim);
+        return GAB_OK;
+    });
+}
+
+int gab_bench_dawsim_stats(gab_bench* b, unsigned long long* waits, unsigned long long* missed_slots) {
+    if (!b) return gab::bad_arg("gab_bench_dawsim_stats: null benchmark");
+    if (waits) *waits = b->last.daw_waits;
+    if (missed_slots) *missed_slots = b->last.daw_missed_slots;
+    return GAB_OK;
+}
+
 }  // extern "C"

@@ -8,6 +8,9 @@
 #include <limits>
 #include <numeric>
 #include <random>
+#include <thread>
+#include <chrono>
+#include <cstdlib>
 
 #include "gab/bench_utils.hpp"
 #include "gab/globals.hpp"
@@ -245,6 +248,101 @@ void collectLatencies(std::vector<float>& latencies, std::function<void()> bench
     latencies.reserve(iterations);
     for (int i = 0; i < iterations; ++i)
         latencies.push_back(static_cast<float>(BenchmarkTimer::measureKernel(benchmark)));
+}
+
+// ---- DAW-style pacing ------------------------------------------------------------
+double DAWSimulator::now() {
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+
+void DAWSimulator::wait(DAWSimulationState& st) const {
+    const double t = now();
+    if (!st.started) {
+        st.started = true;
+        st.next_start = t + bufferDuration;
+    }
+    double jitter = 0.0;
+    if (jitterSeconds > 0.0) {
+        unsigned int x = st.rng;                       // xorshift32 -> U(-j, +j)
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        st.rng = x;
+        jitter = ((double)x / 4294967295.0 * 2.0 - 1.0) * jitterSeconds;
+    }
+    const double target = st.next_start + jitter;
+    ++st.waits;
+    if (target > t) {
+        if (mode == DAWSimulationMode::SLEEP)
+            std::this_thread::sleep_for(std::chrono::duration<double>(target - t));
+        else
+            while (now() < target) {}
+    } else {
+        ++st.late;
+    }
+    st.next_start += bufferDuration;                   // slots stay on the grid, late or not
+}
+
+// ---- harness configuration ---------------------------------------------------------
+BenchmarkConfig BenchmarkConfig::fromCommandLine(int argc, char** argv) {
+    BenchmarkConfig c;
+    struct IntFlag { const char* name; int BenchmarkConfig::*field; };
+    struct BoolFlag { const char* name; bool BenchmarkConfig::*field; bool value; };
+    static const IntFlag ints[] = {
+        {"--buffersize", &BenchmarkConfig::bufferSize}, {"--ntracks", &BenchmarkConfig::trackCount},
+        {"--fs", &BenchmarkConfig::sampleRate},         {"--nruns", &BenchmarkConfig::iterations},
+        {"--warmup", &BenchmarkConfig::warmupIterations}, {"--blocksize", &BenchmarkConfig::preferredBlockSize},
+    };
+    static const BoolFlag bools[] = {
+        {"--validate", &BenchmarkConfig::enableValidation, true},
+        {"--profile", &BenchmarkConfig::enableProfiling, true},
+        {"--verbose", &BenchmarkConfig::verboseOutput, true},
+        {"--no-file", &BenchmarkConfig::writeToFile, false},
+        {"--quiet", &BenchmarkConfig::printStatistics, false},
+        {"--optimal-occupancy", &BenchmarkConfig::useOptimalOccupancy, true},
+        {"--dawsim", &BenchmarkConfig::enableDAWSimulation, true},
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string a(argv[i]);
+        const bool more = i + 1 < argc;
+        bool taken = false;
+        for (const IntFlag& f : ints)
+            if (a == f.name && more) { c.*(f.field) = std::atoi(argv[++i]); taken = true; break; }
+        if (taken) continue;
+        for (const BoolFlag& f : bools)
+            if (a == f.name) { c.*(f.field) = f.value; taken = true; break; }
+        if (taken) continue;
+        if (a == "--output" && more) c.outputDirectory = argv[++i];
+        else if (a == "--prefix" && more) c.outputPrefix = argv[++i];
+    }
+    return c;
+}
+
+bool BenchmarkConfig::validate() const {
+    struct Range { const char* what; int value, lo, hi; };
+    const Range checks[] = {
+        {"buffer size", bufferSize, 1, 8192},
+        {"track count", trackCount, 1, 2048},
+        {"iterations", iterations, 1, 10000},
+        {"block size", preferredBlockSize, 32, 1024},
+    };
+    for (const Range& r : checks)
+        if (r.value < r.lo || r.value > r.hi) {
+            std::cerr << "Invalid " << r.what << ": " << r.value << std::endl;
+            return false;
+        }
+    return true;
+}
+
+void BenchmarkConfig::print() const {
+    std::cout << "=== Benchmark Configuration ===\n"
+              << "Buffer Size: " << bufferSize << " samples\n"
+              << "Track Count: " << trackCount << "\n"
+              << "Sample Rate: " << sampleRate << " Hz\n"
+              << "Iterations: " << iterations << "\n"
+              << "Warmup: " << warmupIterations << "\n"
+              << "Validation: " << (enableValidation ? "ON" : "OFF") << "\n"
+              << "Profiling: " << (enableProfiling ? "ON" : "OFF") << "\n"
+              << "===============================" << std::endl;
 }
 
 // ---- generators -----------------------------------------------------------------

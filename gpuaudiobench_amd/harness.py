@@ -57,6 +57,35 @@ def write_csv_results(latencies, name, filename):
                                     filename.encode()))
 
 
+class DawSim:
+    """Buffer-slot scheduler: wait() returns at t0 + k*buffer_seconds (+/- jitter), spinning or
+    sleeping (metal-swift/MetalSwiftBench/Core/BenchmarkUtilities.swift:140-178)."""
+    MODES = {"spin": 0, "sleep": 1}
+
+    def __init__(self, buffer_seconds=512.0 / 48000.0, mode="spin", jitter_us=0.0):
+        self._h = C.c_void_p()
+        check(lib.gab_dawsim_create(C.byref(self._h), buffer_seconds, self.MODES[mode], jitter_us * 1e-6))
+
+    def wait(self):
+        check(lib.gab_dawsim_wait(self._h))
+
+    def stats(self):
+        w, m = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib.gab_dawsim_stats(self._h, C.byref(w), C.byref(m)))
+        return w.value, m.value
+
+    def close(self):
+        if self._h:
+            lib.gab_dawsim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Benchmark:
     """GPUABenchmark by registry name: setup() / run() / validate()."""
 
@@ -93,6 +122,16 @@ class Benchmark:
         buf = (C.c_float * capacity)()
         n = lib.gab_bench_latencies(self._h, buf, capacity)
         return np.array(buf[:n], np.float32)
+
+    def set_dawsim(self, buffer_seconds=512.0 / 48000.0, mode="spin", jitter_us=0.0, enable=True):
+        """Pace every iteration of run() to one buffer slot (DAWSimulator of the Metal port)."""
+        check(lib.gab_bench_set_dawsim(self._h, 1 if enable else 0, buffer_seconds,
+                                       DawSim.MODES[mode], jitter_us * 1e-6))
+
+    def dawsim_stats(self):
+        w, m = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib.gab_bench_dawsim_stats(self._h, C.byref(w), C.byref(m)))
+        return w.value, m.value
 
     def close(self):
         if self._h:

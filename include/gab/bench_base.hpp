@@ -42,6 +42,9 @@ public:
         double samples_per_sec;
         size_t bytes_processed;
         float mean_latency_ms;
+        // DAW pacing of this run (additive; zero when no simulator was set)
+        unsigned long long daw_waits = 0;
+        unsigned long long daw_missed_slots = 0;
     };
 
     enum class ValidationStatus { SUCCESS = 0, FAILURE = 1, FATAL = -1 };
@@ -74,6 +77,8 @@ protected:
     size_t track_count_;
     float current_iteration_gpu_ms_ = 0.0f;
     hipStream_t stream_ = nullptr;             // all of this benchmark's device work
+    BenchmarkUtils::DAWSimulator daw_simulator_;
+    bool daw_enabled_ = false;
 
 public:
     GPUABenchmark(const std::string& name, size_t buffer_size = BUFSIZE, size_t track_count = NTRACKS);
@@ -91,6 +96,13 @@ public:
     virtual void resetState() {}
     virtual void runValidationIteration() { resetState(); performBenchmarkIteration(); }
     virtual size_t algorithmicBytes() const { return 2 * getTotalElements() * sizeof(float); }
+
+    // DAW-style pacing (metal-swift Core/GPUABenchmark.swift:90,358-392): when set, every
+    // warm-up and timed iteration is followed by a wait for the next buffer slot.
+    void setDawSimulator(const BenchmarkUtils::DAWSimulator& sim) { daw_simulator_ = sim; daw_enabled_ = true; }
+    void clearDawSimulator() { daw_enabled_ = false; }
+    bool hasDawSimulator() const { return daw_enabled_; }
+    const BenchmarkUtils::DAWSimulator& dawSimulator() const { return daw_simulator_; }
 
     // ---- provided (bench_base.cuh:103-110) -----------------------------------------
     void allocateBuffers(size_t element_count);

@@ -130,6 +130,57 @@ using CudaEventTimer = HipEventTimer;
 
 void collectLatencies(std::vector<float>& latencies, std::function<void()> benchmark, int iterations);
 
+// ---- DAW-style pacing ------------------------------------------------------------
+// The CUDA reference only declares the knobs (cuda/globals.cuh:27-30 ENABLE_DAWSIM_SLEEP /
+// SLEEP_MS / ENABLE_DAWSIM_SPIN, cuda/bench_utils.cuh:57-58,95 --dawsim); the scheduler itself
+// exists in its Metal port (metal-swift/MetalSwiftBench/Core/BenchmarkUtilities.swift:140-178):
+// iteration k+1 may not start before t0 + (k+1)*bufferDuration (+/- jitter), reached by
+// sleeping or spinning, so latencies are measured with the device idle between buffers the
+// way a DAW's audio callback leaves it.
+enum class DAWSimulationMode { SPIN, SLEEP };
+
+struct DAWSimulationState {
+    bool started = false;
+    double next_start = 0.0;          // seconds on the steady clock
+    unsigned long long waits = 0;     // calls so far
+    unsigned long long late = 0;      // calls that found their slot already past (a missed deadline)
+    unsigned int rng = 0x9E3779B9u;   // jitter source (xorshift32); fixed seed: runs are repeatable
+};
+
+struct DAWSimulator {
+    double bufferDuration = 512.0 / 48000.0;   // seconds: BUFSIZE / FS
+    DAWSimulationMode mode = DAWSimulationMode::SPIN;
+    double jitterSeconds = 0.0;
+
+    static double now();                       // steady clock, seconds
+    void wait(DAWSimulationState& state) const;
+};
+
+// ---- harness configuration (cuda/bench_utils.cuh:36-132) ---------------------------
+// Declared by the reference, not read by its main.cu; kept so code written against it compiles.
+struct BenchmarkConfig {
+    int bufferSize = 512;
+    int trackCount = 128;
+    int sampleRate = 48000;
+    int iterations = 100;
+    int warmupIterations = 3;
+    bool enableValidation = false;
+    bool enableProfiling = false;
+    bool verboseOutput = false;
+    std::string outputDirectory = "/tmp";
+    std::string outputPrefix = "";
+    bool writeToFile = true;
+    bool printStatistics = true;
+    int preferredBlockSize = 256;
+    bool useOptimalOccupancy = false;
+    bool enableDAWSimulation = false;
+    int dawSleepMs = 90;
+
+    static BenchmarkConfig fromCommandLine(int argc, char** argv);
+    bool validate() const;            // same limits and messages as the reference (:104-131)
+    void print() const;
+};
+
 // ---- data generation (cuda/bench_utils.cuh:213-240) ----------------------------
 void generateRandomAudioData(float* buffer, size_t samples, unsigned int seed = 42);
 

@@ -247,6 +247,22 @@ int  gab_bench_algorithmic_bytes(gab_bench* b, size_t* bytes);
 /* latencies of the last run (ms); returns how many were copied               */
 int  gab_bench_latencies(gab_bench* b, float* out, int capacity);
 
+/* ---- DAW-style pacing --------------------------------------------------------
+ * The CUDA reference declares the knobs only (cuda/globals.cuh:27-30,
+ * cuda/bench_utils.cuh:57-58,95 "--dawsim"); the scheduler is its Metal port's
+ * DAWSimulator (metal-swift/MetalSwiftBench/Core/BenchmarkUtilities.swift:140-178,
+ * used by Core/GPUABenchmark.swift:358-392): iteration k+1 starts no earlier
+ * than t0 + (k+1)*buffer_seconds (+/- jitter).  mode: 0 spin, 1 sleep.          */
+typedef struct gab_dawsim gab_dawsim;
+int gab_dawsim_create(gab_dawsim** s, double buffer_seconds, int mode, double jitter_seconds);
+int gab_dawsim_wait(gab_dawsim* s);
+int gab_dawsim_stats(const gab_dawsim* s, unsigned long long* waits, unsigned long long* missed_slots);
+int gab_dawsim_destroy(gab_dawsim* s);
+/* pace every warm-up and timed iteration of gab_bench_run (enable = 0 turns it off) */
+int gab_bench_set_dawsim(gab_bench* b, int enable, double buffer_seconds, int mode, double jitter_seconds);
+/* pacing counters of the last gab_bench_run */
+int gab_bench_dawsim_stats(gab_bench* b, unsigned long long* waits, unsigned long long* missed_slots);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,27 @@ def test_driver_json_and_unknown_name():
     r = run_driver("--benchmark", "nope")
     assert r.returncode == 1 and "Unknown benchmark 'nope'" in r.stdout
     assert run_driver("--benchmark").returncode == 1
+
+
+def test_dawsim_paces_the_harness_loop(gab):
+    """--dawsim: every warm-up and timed iteration is followed by a wait for the next slot
+    (metal-swift Core/GPUABenchmark.swift:358-392), so a run lasts iterations x slot."""
+    import time
+    b = gab.Benchmark("gain", n_tracks=128)
+    b.setup()
+    slot = 0.002
+    b.set_dawsim(buffer_seconds=slot, mode="spin")
+    t0 = time.perf_counter()
+    r = b.run(iterations=20, warmup=3)
+    elapsed = time.perf_counter() - t0
+    waits, missed = b.dawsim_stats()
+    assert waits == 23 and missed == 0
+    assert 23 * slot - 1e-4 <= elapsed < 23 * slot + 0.02
+    assert r.median_ms < slot * 1e3                     # latencies exclude the wait
+    v, _ = b.validate()
+    assert v.status == 0
+    b.set_dawsim(enable=False)
+    t0 = time.perf_counter()
+    b.run(iterations=20, warmup=3)
+    assert time.perf_counter() - t0 < 23 * slot         # unpaced again
+    b.close()

@@ -88,3 +88,55 @@ def test_bench_config_validation():
         gab.Benchmark("not-a-benchmark")
     with pytest.raises(TypeError):
         gab.Benchmark("gain", bogus=1)
+
+
+# ---- DAW-style pacing (metal-swift Core/BenchmarkUtilities.swift:140-178) ----------
+@pytest.mark.parametrize("mode", ["spin", "sleep"])
+def test_dawsim_keeps_the_buffer_grid(mode):
+    import time
+    slot = 0.004
+    sim = gab.harness.DawSim(buffer_seconds=slot, mode=mode)
+    t0 = time.perf_counter()
+    n = 12
+    for _ in range(n):
+        sim.wait()                       # first call fixes the grid: returns at t0 + slot
+    elapsed = time.perf_counter() - t0
+    assert n * slot - 1e-4 <= elapsed < n * slot + (0.010 if mode == "sleep" else 0.003)
+    waits, missed = sim.stats()
+    assert waits == n and missed == 0
+    sim.close()
+
+
+def test_dawsim_counts_missed_slots_and_stays_on_grid():
+    import time
+    slot = 0.003
+    sim = gab.harness.DawSim(buffer_seconds=slot, mode="spin")
+    sim.wait()
+    time.sleep(2.5 * slot)               # an "iteration" that overruns two slots
+    t0 = time.perf_counter()
+    sim.wait()                           # slot 2 is already past: returns at once, counted as missed
+    assert time.perf_counter() - t0 < 0.5 * slot
+    sim.wait()                           # slot 3 is past as well (2.5 slots slept) or nearly due
+    sim.wait()
+    waits, missed = sim.stats()
+    assert waits == 4 and 1 <= missed <= 2
+    sim.close()
+
+
+def test_dawsim_jitter_is_bounded_and_rejects_bad_arguments():
+    import time
+    slot, jit_us = 0.002, 500.0
+    sim = gab.harness.DawSim(buffer_seconds=slot, mode="spin", jitter_us=jit_us)
+    t0 = time.perf_counter()
+    stamps = []
+    for _ in range(20):
+        sim.wait()
+        stamps.append(time.perf_counter() - t0)
+    # k-th return lies within +/- jitter of the grid point (k+1)*slot (plus scheduling slack)
+    for k, t in enumerate(stamps):
+        assert (k + 1) * slot - jit_us * 1e-6 - 2e-4 <= t <= (k + 1) * slot + jit_us * 1e-6 + 2e-3
+    sim.close()
+    with pytest.raises(gab.GabError):
+        gab.harness.DawSim(buffer_seconds=0.0)
+    with pytest.raises(gab.GabError):
+        gab.harness.DawSim(buffer_seconds=0.01, jitter_us=-1.0)
