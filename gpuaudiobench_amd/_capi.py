@@ -80,6 +80,8 @@ PROTOTYPES = {
     "gab_conv1d": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gab_rndmem": (_I, [_P, _P, _P, _I, _I, _P]),
     "gab_modal": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gab_modal_bank_workspace_bytes": (_Z, [_I, _I, _I]),
+    "gab_modal_bank": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "gab_dwg_workspace_bytes": (_Z, [_I, _I]),
     "gab_dwg": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gab_fft_r2c_1024": (_I, [_P, _P, _I, _P]),

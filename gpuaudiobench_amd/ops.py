@@ -87,6 +87,21 @@ def modal(params, n_modes, bufsize, out_tracks=32):
     return out
 
 
+def modal_bank_workspace(n_modes, bufsize, out_tracks=32, device="cuda"):
+    nbytes = lib.gab_modal_bank_workspace_bytes(n_modes, out_tracks, bufsize)
+    return torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=device)
+
+
+def modal_bank(params, n_modes, bufsize, out_tracks=32, out=None, workspace=None):
+    """The real bank (Metal kernel semantics) on 8-float mode records; returns [out_tracks*bufsize]."""
+    if out is None:
+        out = torch.empty(out_tracks * bufsize, dtype=torch.float32, device=params.device)
+    if workspace is None:
+        workspace = modal_bank_workspace(n_modes, bufsize, out_tracks, params.device)
+    check(lib.gab_modal_bank(_dev(params), _dev(out), n_modes, bufsize, out_tracks, _dev(workspace), _stream()))
+    return out
+
+
 def dwg(wg_bytes, fwd, bwd, x, bufsize, max_len=2000, out_tracks=None, variant=DWG_ACCEL):
     """wg_bytes: uint8 device tensor holding n_wg WaveguideState records (32 B each)."""
     n_wg = wg_bytes.numel() // C.sizeof(WaveguideState)

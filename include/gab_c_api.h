@@ -97,6 +97,16 @@ int gab_rndmem(const float* d_pool, const int* d_playheads, float* d_out,
 int gab_modal(const float* d_params, float* d_out, int n_modes, int bufsize,
               int out_tracks, gab_stream_t stream);
 
+/* The real bank — the reference's Metal kernel BenchmarkModalFilterBank
+ * (metal-swift/MetalSwiftBench/Metal/kernels_benchmark_staging.metal:121-162; golden
+ * Benchmarks/ModalFilterBankBenchmark.swift:73-101) on the same 8-float parameter
+ * records: out[(m % out_tracks)*B + i] = sum over modes of amp * Re(state * e^{i 2 pi f (i+1)}),
+ * fp32 phasor recurrence, fixed summation order (no atomics).  out_tracks in 1..64;
+ * d_params 16-byte aligned; d_workspace holds gab_modal_bank_workspace_bytes().  */
+size_t gab_modal_bank_workspace_bytes(int n_modes, int out_tracks, int bufsize);
+int gab_modal_bank(const float* d_params, float* d_out, int n_modes, int bufsize, int out_tracks,
+                   float* d_workspace, gab_stream_t stream);
+
 /* WaveguideState (cuda/bench_dwg.cuh:19-28), 32 bytes.                       */
 typedef struct {
     int   length, inputTapPos, outputTapPos, writePos;

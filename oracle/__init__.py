@@ -235,6 +235,21 @@ def modal_params(n_modes):
     return p
 
 
+def modal_bank(params, n_modes, bufsize, out_tracks=32):
+    """The real bank: Metal golden (ModalFilterBankBenchmark.swift:73-101), fp32, mode order."""
+    params = np.ascontiguousarray(params, np.float32)
+    out = np.zeros(out_tracks * bufsize, np.float32)
+    lib().orc_modal_bank(_p(params), _p(out), C.c_int(n_modes), C.c_int(bufsize), C.c_int(out_tracks))
+    return out
+
+
+def modal_bank_f64acc(params, n_modes, bufsize, out_tracks=32):
+    params = np.ascontiguousarray(params, np.float32)
+    out = np.zeros(out_tracks * bufsize, np.float64)
+    lib().orc_modal_bank_f64acc(_p(params), _p(out), C.c_int(n_modes), C.c_int(bufsize), C.c_int(out_tracks))
+    return out
+
+
 def modal(params, n_modes, bufsize, out_tracks=32):
     params = _f32(params)
     out = np.empty(bufsize * out_tracks, np.float32)

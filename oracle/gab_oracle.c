@@ -362,6 +362,49 @@ void orc_modal_params(float* params, int n_modes) {
     }
 }
 
+/* metal-swift .../ModalFilterBankBenchmark.swift:73-101 */
+static void modal_bank_rotation(float freq, float* c, float* s) {
+    const float ang = 2.0f * 3.14159265358979323846f * freq;   /* 2.0 * Float.pi * freq, fp32 */
+    *c = (float)cos((double)ang);
+    *s = (float)sin((double)ang);
+}
+
+void orc_modal_bank(const float* params, float* out, int n_modes, int bufsize, int out_tracks) {
+    memset(out, 0, sizeof(float) * (size_t)bufsize * out_tracks);
+    for (int m = 0; m < n_modes; ++m) {
+        const float* p = params + (size_t)m * 8;
+        const float amp = p[0];
+        float re = p[3], im = p[4], c, s;
+        modal_bank_rotation(p[1], &c, &s);
+        float* o = out + (size_t)(m % out_tracks) * bufsize;
+        for (int i = 0; i < bufsize; ++i) {
+            const float a = re * c, b = im * s, d = re * s, e = im * c;
+            re = a - b;
+            im = d + e;
+            const float contrib = amp * re;
+            o[i] = o[i] + contrib;
+        }
+    }
+}
+
+void orc_modal_bank_f64acc(const float* params, double* out, int n_modes, int bufsize, int out_tracks) {
+    memset(out, 0, sizeof(double) * (size_t)bufsize * out_tracks);
+    for (int m = 0; m < n_modes; ++m) {
+        const float* p = params + (size_t)m * 8;
+        const float amp = p[0];
+        float re = p[3], im = p[4], c, s;
+        modal_bank_rotation(p[1], &c, &s);
+        double* o = out + (size_t)(m % out_tracks) * bufsize;
+        for (int i = 0; i < bufsize; ++i) {
+            const float a = re * c, b = im * s, d = re * s, e = im * c;
+            re = a - b;
+            im = d + e;
+            const float contrib = amp * re;
+            o[i] += (double)contrib;
+        }
+    }
+}
+
 /* bench_modal.cu:152-179 */
 void orc_modal(const float* params, float* out, int n_modes, int bufsize,
                int out_tracks) {

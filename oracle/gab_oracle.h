@@ -100,6 +100,19 @@ void orc_conv_accel_stream(const float* in, const float* ir, float* out,
 void orc_conv_accel_stream_f64(const float* in, const float* ir, double* out,
                                float* hist, int ir_len, int bufsize, int tracks);
 
+/* ---- modal: the real bank ------------------------------------
+ * Golden of the reference's Metal port (metal-swift/MetalSwiftBench/Benchmarks/
+ * ModalFilterBankBenchmark.swift:73-101; kernel Metal/kernels_benchmark_staging.metal
+ * :121-162): mode m = (amp, freq, -, re, im, ...) is a complex phasor rotated by
+ * 2*pi*freq per sample, out[(m % tracks)*B + i] += amp * re_i, fp32, modes in
+ * index order.  The rotation's (cos, sin) are (float)cos/sin((double)(2*pi_f*freq)):
+ * the reference calls cosf/sinf, whose last bit is library-dependent; this
+ * definition is reproducible on host and device alike.  "Parity unpinned": the
+ * reference holds no fixture for it (its parameters are unseeded Float.random). */
+void orc_modal_bank(const float* params, float* out, int n_modes, int bufsize, int out_tracks);
+/* same per-mode fp32 phasor sequences, accumulated in float64 (summation-order-free check) */
+void orc_modal_bank_f64acc(const float* params, double* out, int n_modes, int bufsize, int out_tracks);
+
 /* ---- modal (placeholder semantics of the CUDA port) -------------------- */
 void orc_modal_params(float* params, int n_modes);            /* srand(42) */
 void orc_modal(const float* params, float* out, int n_modes, int bufsize,

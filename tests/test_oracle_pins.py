@@ -168,6 +168,26 @@ def test_modal(orc):
     assert orc.fnv_survey(y) == "4061a3942e534783"
 
 
+def test_modal_bank_golden_restatement(orc):
+    """Real bank (Metal golden, ModalFilterBankBenchmark.swift:73-101): analytic single modes,
+    round-robin track mapping, and agreement with its float64-accumulated twin."""
+    q = np.zeros(8, np.float32)
+    q[0], q[1], q[3] = 0.5, 0.125, 1.0                       # amp, freq, re (im = 0)
+    y = orc.modal_bank(q, 1, 16, 1)
+    want = 0.5 * np.cos(2 * np.pi * 0.125 * np.arange(1, 17))
+    assert np.abs(y - want).max() < 2e-7
+    # mode m lands on track m % tracks
+    p = np.zeros(5 * 8, np.float32)
+    for m in range(5):
+        p[8 * m + 0] = m + 1.0
+        p[8 * m + 3] = 1.0                                    # freq 0: state stays (1, 0)
+    y = orc.modal_bank(p, 5, 4, 3).reshape(3, 4)
+    assert np.array_equal(y[:, 0], np.array([1.0 + 4.0, 2.0 + 5.0, 3.0], np.float32))
+    p = orc.modal_params(20000)
+    a, b = orc.modal_bank(p, 20000, 64, 32), orc.modal_bank_f64acc(p, 20000, 64, 32)
+    assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
+
+
 def test_statistics(orc):
     lat = np.array([1.0, 2.0, 3.0, 4.0, 10.0], np.float32)
     s = orc.statistics(lat)
