@@ -33,6 +33,7 @@ void printHelp() {
     printf("  --irLength [taps]   Impulse-response length for Conv1D / Conv1D_accel\n");
     printf("  --fdtdGrid [n]      FDTD3D grid edge including the boundary shell (default: 52)\n");
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
+    printf("  --modalMode [m]     ModalFilterBank: placeholder (the CUDA port, default) | bank (real phasor bank)\n");
     printf("  --dawsim            Pace iterations to one buffer slot each (bufferSize / fs)\n");
     printf("  --dawsim-mode [m]   spin | sleep (default: spin)\n");
     printf("  --dawsim-jitter-us [us]  Uniform jitter on each slot (default: 0)\n");
@@ -153,6 +154,9 @@ int main(int argc, char** argv) {
         else if (strcmp(argv[i], "--convMode") == 0) {
             if (!need("--convMode")) return 1;
             CONV_STREAMING = strcmp(argv[++i], "stateless") == 0 ? 0 : 1;
+        } else if (strcmp(argv[i], "--modalMode") == 0) {
+            if (!need("--modalMode")) return 1;
+            MODAL_REAL = strcmp(argv[++i], "bank") == 0 ? 1 : 0;
         } else if (strcmp(argv[i], "--dawsim") == 0) {
             g_dawsim = true;
         } else if (strcmp(argv[i], "--dawsim-mode") == 0) {

@@ -102,6 +102,7 @@ void gab_bench_default_config(gab_bench_config* c) {
     c->fdtd_grid = 0;
     c->conv_mode = GAB_CONV_STREAMING;
     c->quiet = 1;
+    c->modal_mode = 0;
 }
 
 int gab_bench_count(void) { return static_cast<int>(gab::benchmarkNames().size()); }
@@ -124,6 +125,7 @@ int gab_bench_create(gab_bench** out, const char* name, const gab_bench_config* 
         IR_LENGTH = c.ir_length; FDTD_GRID = c.fdtd_grid;
         CONV_STREAMING = (c.conv_mode == GAB_CONV_STREAMING) ? 1 : 0;
         GAB_QUIET = c.quiet != 0;
+        MODAL_REAL = c.modal_mode != 0;
         auto impl = gab::createBenchmark(name);
         if (!impl) return gab::bad_arg("gab_bench_create: unknown benchmark name");
         auto* b = new gab_bench;

@@ -136,6 +136,29 @@ void modal(const float* params, float* out, int n_modes, int B, int out_tracks) 
     }
 }
 
+// Mode m: phasor (re, im) turned by 2*pi*freq per sample, out[(m % tracks)*B + i] += amp*re,
+// fp32, modes in index order.  (cos, sin) = (float)cos/sin((double)angle): reproducible on
+// host and device (the reference's cosf/sinf differ in the last bit between libraries).
+void modal_bank(const float* params, float* out, int n_modes, int B, int out_tracks) {
+    std::memset(out, 0, sizeof(float) * static_cast<size_t>(B) * out_tracks);
+    for (int m = 0; m < n_modes; ++m) {
+        const float* p = params + static_cast<size_t>(m) * ModalBenchmark::NUM_MODE_PARAMS;
+        const float amp = p[ModalBenchmark::AMPLITUDE];
+        const float ang = 2.0f * 3.14159265358979323846f * p[ModalBenchmark::FREQUENCY];
+        const float c = static_cast<float>(std::cos(static_cast<double>(ang)));
+        const float s = static_cast<float>(std::sin(static_cast<double>(ang)));
+        float re = p[ModalBenchmark::STATE_REAL], im = p[ModalBenchmark::STATE_IMAG];
+        float* o = out + static_cast<size_t>(m % out_tracks) * B;
+        for (int i = 0; i < B; ++i) {
+            const float a = re * c, b = im * s, d = re * s, e = im * c;
+            re = a - b;
+            im = d + e;
+            const float contrib = amp * re;
+            o[i] = o[i] + contrib;
+        }
+    }
+}
+
 void dwg(const WaveguideState* wgs, float* fwd, float* bwd, const float* in, float* out,
          const DWGParams* p) {
     std::memset(out, 0, sizeof(float) * p->bufferSize);

@@ -28,6 +28,8 @@ void iir(const float* in, float* out, const IIRCoefficients* c, float* state, in
 void conv1d(const float* in, const float* ir, float* out, int L, int B, int T);  // bench_conv1d.cu:188-208
 void conv_accel(const float* in, const float* ir, float* out, int L, int B, int T);  // bench_conv1d_accel.cu:234-252
 void modal(const float* params, float* out, int n_modes, int B, int out_tracks); // bench_modal.cu:152-179
+// the real bank: metal-swift/MetalSwiftBench/Benchmarks/ModalFilterBankBenchmark.swift:73-101
+void modal_bank(const float* params, float* out, int n_modes, int B, int out_tracks);
 void dwg(const WaveguideState* wg, float* fwd, float* bwd, const float* in, float* out,
          const DWGParams* p);                                                      // bench_dwg.cu:356-399
 void fdtd_placeholder(const float* in, float* out, size_t T, size_t B);          // bench_fdtd3d.cu:445-459

@@ -27,6 +27,7 @@ bool JSON_OUTPUT = false;
 int IR_LENGTH = 0;
 int FDTD_GRID = 0;
 int CONV_STREAMING = 1;
+int MODAL_REAL = 0;
 bool GAB_QUIET = false;
 
 namespace {

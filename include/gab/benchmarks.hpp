@@ -261,19 +261,30 @@ public:
     static const int MODAL_OUTPUT_TRACKS = 32;
     enum ModeParams { AMPLITUDE = 0, FREQUENCY = 1, PHASE = 2, STATE_REAL = 3, STATE_IMAG = 4,
                       RESERVED1 = 5, RESERVED2 = 6, RESERVED3 = 7 };
-    ModalBenchmark();
+    // PLACEHOLDER: the CUDA port as it is (32 constants, 32 MiB parameter upload per iteration).
+    // BANK: the bank the benchmark is named for — the reference's Metal kernel
+    // (kernels_benchmark_staging.metal:121-162) on the same parameter records: min(1024*NTRACKS,
+    // 2^20) modes onto min(NTRACKS, 32) tracks, parameters resident on the device.
+    enum class Variant { PLACEHOLDER, BANK };
+    explicit ModalBenchmark(Variant variant = MODAL_REAL ? Variant::BANK : Variant::PLACEHOLDER);
     ~ModalBenchmark() override;
     void setupBenchmark() override;
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
     size_t algorithmicBytes() const override;
+    int modeCount() const { return num_modes_; }
+    int outputTracks() const { return out_tracks_; }
 
 private:
+    Variant variant_;
+    int num_modes_;
+    int out_tracks_;
     float* h_mode_params = nullptr;
     float* d_mode_params = nullptr;
     float* h_modal_output = nullptr;
     float* d_modal_output = nullptr;
+    float* d_workspace = nullptr;
     float* cpu_reference = nullptr;
     size_t mode_params_size;
     size_t mode_params_bytes;

@@ -17,6 +17,7 @@ extern bool JSON_OUTPUT;         // --json
 extern int IR_LENGTH;            // --irLength     (<=0: each benchmark's DEFAULT_IR_LEN)
 extern int FDTD_GRID;            // --fdtdGrid     (<=0: 52, the reference's 50+2)
 extern int CONV_STREAMING;       // --convMode stream|stateless (default stream)
+extern int MODAL_REAL;           // --modalMode placeholder|bank (default placeholder = the CUDA port)
 extern bool GAB_QUIET;           // suppress progress chatter (library use)
 
 // DAW-simulation knobs exist in the reference as compile-time macros, all off

@@ -227,6 +227,8 @@ typedef struct {
     int    fdtd_grid;       /* <=0: 52 (bench_fdtd3d.cuh:36-38)                */
     int    conv_mode;       /* GAB_CONV_*                                      */
     int    quiet;           /* suppress the reference's progress printf        */
+    int    modal_mode;      /* ModalFilterBank: 0 the CUDA port's placeholder
+                               (bench_modal.cu:15-36), 1 the real bank (Metal port) */
 } gab_bench_config;
 
 typedef struct {

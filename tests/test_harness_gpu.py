@@ -122,3 +122,17 @@ def test_dawsim_paces_the_harness_loop(gab):
     b.run(iterations=20, warmup=3)
     assert time.perf_counter() - t0 < 23 * slot         # unpaced again
     b.close()
+
+
+@pytest.mark.parametrize("tracks", [8, 128])
+def test_modal_real_bank_through_the_harness(gab, tracks):
+    """modal_mode=1: the Metal port's bank (min(1024*tracks, 2^20) modes onto min(tracks, 32)
+    rows) validates against its golden; the default stays the CUDA port's placeholder."""
+    b = gab.Benchmark("ModalFilterBank", n_tracks=tracks, buffer_size=128, modal_mode=1)
+    b.setup()
+    r = b.run(iterations=3, warmup=1)
+    v, text = b.validate()
+    assert v.status == 0, text
+    assert r.gpu_median_ms > 0
+    assert b.algorithmic_bytes() == min(1024 * tracks, 1 << 20) * 32 + min(tracks, 32) * 128 * 4
+    b.close()
