@@ -391,7 +391,8 @@ def test_dwg_audible_configuration(gab, orc, variant):
     assert np.abs(ry).max() > 0
 
 
-@pytest.mark.parametrize("n,T,B,samples", [(20, 4, 16, 16), (52, 128, 512, 24), (33, 3, 8, 8)])
+@pytest.mark.parametrize("n,T,B,samples", [(20, 4, 16, 16), (52, 128, 512, 24), (33, 3, 8, 8),
+                                          (128, 16, 8, 6)])      # C4's grid, a few samples
 def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     import torch
     P = orc.fdtd_params(n)
@@ -418,6 +419,30 @@ def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     plan.reset()
     assert not host(plan.pressure()).any()
     plan.close()
+
+
+def test_fdtd_c4_grid_scaling_property(gab, orc):
+    """BASELINE C4 (128^3): every operation of the scheme is linear and a factor 2 is exact in
+    fp32, so doubling the input must double every output bit for bit, at full size."""
+    import torch
+    n, T, B = 128, 16, 32
+    x = orc.Rand(1).bipolar(T * B)
+    fields = []
+    for scale in (1.0, 2.0):
+        plan = gab.FdtdPlan(gab.fdtd_default_params(n))
+        out = torch.zeros(T * B, device="cuda")
+        plan.process(dev((x * np.float32(scale)).astype(np.float32)), out, T, B, 0, B)
+        # 96 steps move the wave ~28 cells: it has not reached the receiver, so the field is compared
+        fields.append(host(plan.pressure()).ravel())
+        plan.close()
+    assert np.count_nonzero(fields[0]) > 10000
+    # exact wherever the values are normal numbers; the numerical precursor of the front runs
+    # through the subnormal range, where x and 2x do not round alike
+    # (products like c1 * dp go subnormal there and their lost bits reach values up to ~1e-27)
+    normal = np.abs(fields[0]) > 1e-20
+    assert np.count_nonzero(normal) > 10000
+    assert np.array_equal(bits(fields[1][normal]), bits(np.float32(2.0) * fields[0][normal]))
+    assert np.abs(fields[1][~normal] - 2.0 * fields[0][~normal]).max() < 1e-25
 
 
 def test_rndmem_small_pool(gab, orc):
