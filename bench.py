@@ -150,6 +150,18 @@ def main():
             rt.append((time.perf_counter() - t1) * 1e6)
     rt = np.array(rt)
 
+    # ---- zero-copy round trip: the kernel reads the pinned input and writes the pinned output
+    # itself (no copy commands); same buffer, same history sequence ----------------------------
+    h_out_zc = torch.empty(T * B, dtype=torch.float32).pin_memory()
+    zc = []
+    for i in range(args.roundtrip_iters + 20):
+        t1 = time.perf_counter()
+        plan.process(h_in, out=h_out_zc, mode=gab.CONV_STREAMING)
+        stream.synchronize()
+        if i >= 20:
+            zc.append((time.perf_counter() - t1) * 1e6)
+    zc = np.array(zc)
+
     # ---- the same round trip under DAW pacing: one buffer per 512/48000 s slot, device idle in
     # between (the Metal port's DAWSimulator) --------------------------------------
     paced = []
@@ -202,6 +214,8 @@ def main():
             "realtime_factor": (world * args.steps / elapsed) * B / FS,
             "p50_round_trip_us": float(np.percentile(rt, 50)),
             "p95_round_trip_us": float(np.percentile(rt, 95)),
+            "p50_round_trip_zero_copy_us": float(np.percentile(zc, 50)),
+            "p95_round_trip_zero_copy_us": float(np.percentile(zc, 95)),
             "paced_10p667ms": {"p50_round_trip_us": float(np.percentile(paced, 50)),
                                "p95_round_trip_us": float(np.percentile(paced, 95)),
                                "max_round_trip_us": float(paced.max()),

@@ -26,6 +26,18 @@ def _dev(t, dtype=torch.float32):
     return C.c_void_p(t.data_ptr())
 
 
+def _acc(t, dtype=torch.float32):
+    """Device-ACCESSIBLE memory: a device tensor, or a pinned host tensor (hipHostMalloc memory is
+    mapped into the device's address space, so a kernel can read and write it over PCIe)."""
+    if isinstance(t, torch.Tensor) and not t.is_cuda and t.is_pinned():
+        if t.dtype != dtype:
+            raise TypeError("expected dtype %s, got %s" % (dtype, t.dtype))
+        if not t.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(t.data_ptr())
+    return _dev(t, dtype)
+
+
 def device_count():
     n = C.c_int(0)
     check(lib.gab_device_count(C.byref(n)))
@@ -138,8 +150,11 @@ class ConvPlan:
     def process(self, x, out=None, mode=CONV_STREAMING):
         assert x.numel() == self.tracks * self.bufsize
         if out is None:
-            out = torch.empty(self.tracks * self.bufsize, dtype=torch.float32, device=x.device)
-        check(lib.gab_conv_process(self._h, _dev(x), _dev(out), mode, _stream()))
+            out = torch.empty(self.tracks * self.bufsize, dtype=torch.float32,
+                              device=x.device if x.is_cuda else "cuda")
+        # x / out may also be pinned host tensors: the kernel then streams the buffer over PCIe
+        # itself (zero-copy), without separate copy commands
+        check(lib.gab_conv_process(self._h, _acc(x), _acc(out), mode, _stream()))
         return out
 
     def state_bytes(self):
