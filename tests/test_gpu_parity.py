@@ -270,6 +270,28 @@ def test_conv_accel_other_shapes_fallback(gab, orc, B, L, T):
     plan.close()
 
 
+def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
+    """d_in / d_out may be pinned host memory: the kernel then moves the buffer over PCIe itself.
+    Same bits as with device buffers and copy commands."""
+    import torch
+    T, B, L = 64, 512, 4096
+    ir = dev(orc.conv_accel_ir(L, T))
+    xs = [orc.noise(T * B, seed=30 + i) for i in range(4)]
+    a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
+    a.set_ir(ir)
+    b.set_ir(ir)
+    h_out = torch.empty(T * B).pin_memory()
+    for x in xs:
+        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+        b.process(torch.from_numpy(x).pin_memory(), out=h_out, mode=gab.CONV_STREAMING)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(ya), bits(h_out.numpy()))
+    with pytest.raises(TypeError):
+        a.process(torch.from_numpy(xs[0]))            # pageable host memory is not device-accessible
+    a.close()
+    b.close()
+
+
 def test_conv_accel_errors(gab):
     import torch
     with pytest.raises(gab.GabError):
