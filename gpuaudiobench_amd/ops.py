@@ -157,6 +157,14 @@ class ConvPlan:
         check(lib.gab_conv_process(self._h, _acc(x), _acc(out), mode, _stream()))
         return out
 
+    def process_batch(self, x, n_buffers, out=None):
+        """n_buffers consecutive buffers ([n][T*B] in, [n][B*T] out) in one launch."""
+        assert x.numel() == n_buffers * self.tracks * self.bufsize
+        if out is None:
+            out = torch.empty(n_buffers * self.tracks * self.bufsize, dtype=torch.float32, device=x.device)
+        check(lib.gab_conv_process_batch(self._h, _dev(x), _dev(out), n_buffers, _stream()))
+        return out
+
     def state_bytes(self):
         a, b = C.c_size_t(0), C.c_size_t(0)
         check(lib.gab_conv_state_bytes(self._h, C.byref(a), C.byref(b)))

@@ -155,6 +155,13 @@ int gab_conv_reset(gab_conv_plan* plan, gab_stream_t stream);
  * (zero-copy round trip: 94 us against 117 us with copy commands at C3).      */
 int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
                      int mode, gab_stream_t stream);
+/* n_buffers consecutive buffers in ONE launch (streaming mode): d_in = [n][T*B]
+ * track-major buffers back to back, d_out = [n][B*T].  Same results as n calls of
+ * gab_conv_process; for callers that have the input ahead of time (offline
+ * rendering): no kernel boundary between buffers, spectra stay cache-resident.
+ * Additive: the reference processes one buffer per iteration.                    */
+int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
+                           int n_buffers, gab_stream_t stream);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
                          size_t* history_bytes);

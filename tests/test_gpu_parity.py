@@ -292,6 +292,28 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
     b.close()
 
 
+@pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (5, 512, 2000, 3), (16, 512, 512, 4), (3, 256, 700, 5)])
+def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
+    """gab_conv_process_batch: n buffers in one launch walk the same history as n launches —
+    same bits — including across two batches and for shapes that take the fallback."""
+    import torch
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
+    a.set_ir(ir)
+    b.set_ir(ir)
+    x = np.concatenate([orc.noise(T * B, seed=60 + i) for i in range(2 * n)])
+    seq = np.concatenate([host(a.process(dev(x[i * T * B:(i + 1) * T * B]), mode=gab.CONV_STREAMING))
+                          for i in range(2 * n)])
+    y1 = host(b.process_batch(dev(x[:n * T * B]), n))
+    y2 = host(b.process_batch(dev(x[n * T * B:]), n))
+    assert np.array_equal(bits(seq), bits(np.concatenate([y1, y2])))
+    with pytest.raises(gab.GabError):
+        lib_rc = gab.lib.gab_conv_process_batch(b._h, None, None, 1, None)
+        gab.check(lib_rc)
+    a.close()
+    b.close()
+
+
 def test_conv_accel_errors(gab):
     import torch
     with pytest.raises(gab.GabError):
