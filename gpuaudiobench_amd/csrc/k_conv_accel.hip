@@ -168,15 +168,12 @@ __device__ unsigned long long g_conv_stamps[8 * 4096];
 // a 512-thread radix-8 form of this kernel (8 values per thread, 4 passes), 16.6 us:
 // the transforms are bound by LDS write bandwidth and VALU throughput, not by the
 // per-thread instruction chain, and radix-8 needs a third exchange.)
-// BATCH: the launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup
-// walks them in order for its pair.  Pairs are independent, so nothing is synchronised between
-// workgroups; a thread re-reads from the ring only what it wrote itself.
-template <bool STREAM, bool TAIL, int ABL = 0, bool BATCH = false>
-__global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
-    const float* __restrict__ in0, float* __restrict__ out0, float* __restrict__ hist,
+// One buffer of one channel pair; the body of both kernels below.
+template <bool STREAM, bool TAIL, int ABL>
+__device__ __forceinline__ void conv_one_buffer(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
-    const cf* __restrict__ tw, int T, int head0, int n_buffers) {
-    __shared__ cf lds[2 * kLdsHalf];
+    const cf* __restrict__ tw, int T, int head, cf* __restrict__ lds) {
     cf* const lds0 = lds;
     cf* const lds1 = lds + kLdsHalf;
 
@@ -184,10 +181,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     const int q = xcd_contiguous(blockIdx.x, gridDim.x);
     const int ta = 2 * q, tb = 2 * q + 1;
     const bool hasb = tb < T;
-  for (int nb = 0; nb < (BATCH ? n_buffers : 1); ++nb) {
-    const float* const in = in0 + (size_t)nb * T * kB;
-    float* const out = out0 + (size_t)nb * T * kB;
-    const int head = (head0 + nb) & (kSlots - 1);
 
     // history ring of this pair: [slot][sample] complex (channel a, channel b)
     cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
@@ -329,7 +322,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
         if (hasb) { o0[1] = yb0; o1[1] = yb1; }
     }
     GAB_STAMP(7);
-  }
+}
+
+template <bool STREAM, bool TAIL, int ABL = 0>
+__global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const float4* __restrict__ pmB,
+    const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalf];
+    conv_one_buffer<STREAM, TAIL, ABL>(in, out, hist, pmA, pmB, tw, T, head, lds);
+}
+
+// The launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup walks them
+// in order for its pair.  Pairs are independent, so nothing is synchronised between workgroups; a
+// thread re-reads from the ring only what it wrote itself; the LDS hand-over rule of the stages
+// holds across iterations (the last stage's final reads are from the buffer the next iteration
+// writes second).
+__global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const float4* __restrict__ pmB,
+    const cf* __restrict__ tw, int T, int head, int n_buffers) {
+    __shared__ cf lds[2 * kLdsHalf];
+    const size_t step = (size_t)T * kB;
+    for (int nb = 0; nb < n_buffers; ++nb)
+        conv_one_buffer<true, true, 0>(in + nb * step, out + nb * step, hist, pmA, pmB, tw, T,
+                                       (head + nb) & (kSlots - 1), lds);
 }
 
 // IR bank -> (P, M) spectra of both partitions.  d_ir is T x L track-major.
@@ -589,7 +606,7 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
         const bool streaming = mode == GAB_CONV_STREAMING;
         if (p->fused) {
             dim3 grid(p->pairs), block(gab::kThreads);
-#define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head, 1
+#define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head
             if (!streaming)
                 gab::conv_overlap_save_kernel<false, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
             else if (!p->tail)
@@ -634,9 +651,9 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
         if (n_buffers <= 0) return gab::bad_arg("gab_conv_process_batch: n_buffers must be > 0");
         hipStream_t s = gab::as_stream(stream);
         if (p->fused && p->tail) {
-            gab::conv_overlap_save_kernel<true, true, 0, true><<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
+            gab::conv_batch_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
                 d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head, n_buffers);
-            int rc = gab::launch_status("conv_overlap_save_kernel (batch)");
+            int rc = gab::launch_status("conv_batch_kernel");
             if (rc) return rc;
             p->head = (p->head + n_buffers) & (gab::kSlots - 1);
             return GAB_OK;
