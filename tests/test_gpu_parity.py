@@ -507,3 +507,69 @@ def test_rndmem_reference_pool_512mib(gab, orc):
     y = host(gab.rndmem(dev(pool), dev(ph), T, B))
     assert orc.fnv_survey(y) == "b59ca490d48ee02c"               # SURVEY §8c pin
     assert np.array_equal(bits(y), bits(orc.rndmem(pool, ph, B)))
+
+
+# ---------------------------------------------------------------- seeded random shapes
+def _rng_shapes(seed, n, lo, hi):
+    r = np.random.RandomState(seed)
+    return [tuple(int(v) for v in r.randint(lo, hi, size=len(lo))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("T,B", _rng_shapes(11, 6, (1, 1), (300, 700)))
+def test_random_shapes_gainstats_and_iir(gab, orc, T, B):
+    import torch
+    x = orc.noise(T * B, seed=T * 1000 + B)
+    out, stats = gab.gainstats(dev(x), T, B, 0.5)
+    ro, rs = orc.gainstats(x, T, B)
+    assert np.array_equal(bits(host(out)), bits(ro))
+    assert np.array_equal(host(stats)[1::2], rs[1::2])                       # max: exact
+    assert np.abs(host(stats)[0::2] - rs[0::2]).max() <= 1e-5                # mean: order-dependent sum
+    c = orc.iir_coeffs(0.25)
+    st_g = torch.zeros(2 * T, device="cuda")
+    st_o = np.zeros(2 * T, np.float32)
+    for k in range(2):
+        xk = orc.noise(T * B, seed=k + 5)
+        yg = host(gab.iir(dev(xk), dev(c), st_g, T, B, sequential=True))
+        yo = orc.iir(xk, c, st_o, T, B)
+        assert np.array_equal(bits(yg), bits(yo))
+    assert np.array_equal(bits(host(st_g)), bits(st_o))
+
+
+@pytest.mark.parametrize("T,L,nbuf", _rng_shapes(23, 5, (1, 513, 2), (40, 4097, 6)))
+def test_random_shapes_streaming_convolution(gab, orc, T, L, nbuf):
+    """Fused path (B = 512) at random channel counts and tap counts in (512, 4096]."""
+    B = 512
+    ir = orc.conv_accel_ir(L, T)
+    plan = gab.ConvPlan(T, B, L)
+    plan.set_ir(dev(ir))
+    hist = np.zeros(T * L, np.float32)
+    peak, worst = 0.0, 0.0
+    for i in range(nbuf + 8):
+        x = orc.noise(T * B, seed=900 + i)
+        y = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
+        ref = orc.conv_accel_stream(x, ir, hist, L, B, T, f64=True)
+        peak = max(peak, float(np.abs(ref).max()))
+        worst = max(worst, float(np.abs(y - ref).max()))
+    assert worst <= 1e-5 * peak
+    plan.close()
+
+
+@pytest.mark.parametrize("T,B", _rng_shapes(37, 4, (1, 8), (200, 600)))
+def test_random_shapes_rndmem_and_modal_bank(gab, orc, T, B):
+    N = 1 << 18
+    pool = orc.rndmem_pool(N)
+    r = np.random.RandomState(T * 7 + B)
+    ph = r.randint(0, N - B, size=T).astype(np.int32)
+    y = host(gab.rndmem(dev(pool), torch_i32(ph), T, B))
+    assert np.array_equal(bits(y), bits(orc.rndmem(pool, ph, B)))
+    tracks = 1 + (T % 32)
+    nm = 37 * T + 5
+    p = orc.modal_params(nm)
+    yb = host(gab.modal_bank(dev(p), nm, B, tracks))
+    ref = orc.modal_bank_f64acc(p, nm, B, tracks)
+    assert np.abs(yb - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def torch_i32(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, np.int32)).cuda()
