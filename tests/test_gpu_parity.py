@@ -314,6 +314,27 @@ def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
     b.close()
 
 
+def test_conv_accel_long_stream_does_not_drift(gab, orc):
+    """400 buffers (the 8-slot ring wraps 50 times; the only carried state is an exact copy of the
+    input): the error against the float64 direct form stays where it was after the first window."""
+    T, B, L = 4, 512, 4096
+    ir = orc.conv_accel_ir(L, T)
+    plan = gab.ConvPlan(T, B, L)
+    plan.set_ir(dev(ir))
+    hist = np.zeros(T * L, np.float32)
+    errs, peaks = [], []
+    for i in range(400):
+        x = orc.noise(T * B, seed=2000 + i)
+        y = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
+        ref = orc.conv_accel_stream(x, ir, hist, L, B, T, f64=True)
+        errs.append(float(np.abs(y - ref).max()))
+        peaks.append(float(np.abs(ref).max()))
+    peak = max(peaks)
+    assert max(errs) <= 1e-5 * peak
+    assert max(errs[300:]) <= 1.5 * max(errs[8:100]) + 1e-12        # no growth over the stream
+    plan.close()
+
+
 def test_conv_accel_errors(gab):
     import torch
     with pytest.raises(gab.GabError):
