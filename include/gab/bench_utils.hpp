@@ -225,6 +225,18 @@ void launchKernel1D(KernelFunc kernel, size_t totalThreads, int preferredBlockSi
     launchKernel(kernel, dim3(gridSize), dim3(blockSize), std::forward<Args>(args)...);
 }
 
+// cuda/bench_utils.cuh:298-318: block size from the occupancy calculator, 256 if it declines.
+template <typename KernelFunc, typename... Args>
+void launchKernelOptimal(KernelFunc kernel, size_t totalThreads, Args&&... args) {
+    int minGridSize = 0, blockSize = 0;
+    if (hipOccupancyMaxPotentialBlockSize(&minGridSize, &blockSize, kernel, 0, 0) != hipSuccess || blockSize <= 0) {
+        launchKernel1D(kernel, totalThreads, 256, std::forward<Args>(args)...);
+        return;
+    }
+    const int gridSize = static_cast<int>((totalThreads + blockSize - 1) / blockSize);
+    launchKernel(kernel, dim3(gridSize), dim3(blockSize), std::forward<Args>(args)...);
+}
+
 template <typename KernelFunc, typename... Args>
 double launchKernelTimed(KernelFunc kernel, dim3 gridDim, dim3 blockDim, Args&&... args) {
     HipEventTimer timer;
