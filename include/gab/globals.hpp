@@ -2,6 +2,9 @@
 // (reference: cuda/globals.cuh:20-42, cuda/globals.cu).  Names and defaults are
 // the reference's; the CSV / JSON formats are byte-compatible with it.
 #pragma once
+// cuda/globals.cuh:37 (a Windows path there; nothing reads it)
+#define OUTFILE "/tmp/latencies.txt"
+
 
 #include <string>
 #include <vector>
