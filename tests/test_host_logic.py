@@ -91,50 +91,55 @@ def test_bench_config_validation():
 
 
 # ---- DAW-style pacing (metal-swift Core/BenchmarkUtilities.swift:140-178) ----------
+# Slots of 10-20 ms and generous upper bounds: these run on shared CI hosts.
 @pytest.mark.parametrize("mode", ["spin", "sleep"])
 def test_dawsim_keeps_the_buffer_grid(mode):
     import time
-    slot = 0.004
+    slot = 0.010
     sim = gab.harness.DawSim(buffer_seconds=slot, mode=mode)
     t0 = time.perf_counter()
-    n = 12
+    n = 10
     for _ in range(n):
         sim.wait()                       # first call fixes the grid: returns at t0 + slot
     elapsed = time.perf_counter() - t0
-    assert n * slot - 1e-4 <= elapsed < n * slot + (0.010 if mode == "sleep" else 0.003)
+    assert elapsed >= n * slot - 1e-4    # never early: that is the contract
+    assert elapsed < n * slot + 0.25     # and not absurdly late
     waits, missed = sim.stats()
-    assert waits == n and missed == 0
+    assert waits == n and missed <= 1    # a descheduled host may overrun one slot
     sim.close()
 
 
 def test_dawsim_counts_missed_slots_and_stays_on_grid():
     import time
-    slot = 0.003
+    slot = 0.020
     sim = gab.harness.DawSim(buffer_seconds=slot, mode="spin")
-    sim.wait()
-    time.sleep(2.5 * slot)               # an "iteration" that overruns two slots
+    sim.wait()                           # returns at t0 + slot; slots 2, 3, ... follow on the grid
+    t_grid = time.perf_counter()
+    time.sleep(2.5 * slot)               # an "iteration" that overruns slots 2 and 3
     t0 = time.perf_counter()
     sim.wait()                           # slot 2 is already past: returns at once, counted as missed
-    assert time.perf_counter() - t0 < 0.5 * slot
-    sim.wait()                           # slot 3 is past as well (2.5 slots slept) or nearly due
-    sim.wait()
+    assert time.perf_counter() - t0 < slot
+    sim.wait()                           # slot 3 too
+    sim.wait()                           # slot 4 = t_grid + 3 slots: waited for
+    assert time.perf_counter() - t_grid >= 3 * slot - 1e-3
     waits, missed = sim.stats()
-    assert waits == 4 and 1 <= missed <= 2
+    assert waits == 4 and missed >= 2
     sim.close()
 
 
 def test_dawsim_jitter_is_bounded_and_rejects_bad_arguments():
     import time
-    slot, jit_us = 0.002, 500.0
+    slot, jit_us = 0.010, 2000.0
     sim = gab.harness.DawSim(buffer_seconds=slot, mode="spin", jitter_us=jit_us)
     t0 = time.perf_counter()
     stamps = []
-    for _ in range(20):
+    for _ in range(12):
         sim.wait()
         stamps.append(time.perf_counter() - t0)
-    # k-th return lies within +/- jitter of the grid point (k+1)*slot (plus scheduling slack)
+    # the k-th return is never earlier than its grid point minus the jitter
     for k, t in enumerate(stamps):
-        assert (k + 1) * slot - jit_us * 1e-6 - 2e-4 <= t <= (k + 1) * slot + jit_us * 1e-6 + 2e-3
+        assert t >= (k + 1) * slot - jit_us * 1e-6 - 5e-4
+    assert stamps[-1] < 12 * slot + 0.25
     sim.close()
     with pytest.raises(gab.GabError):
         gab.harness.DawSim(buffer_seconds=0.0)
