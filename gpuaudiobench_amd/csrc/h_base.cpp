@@ -7,7 +7,7 @@
 #include "gab/bench_base.hpp"
 #include "gab_c_api.h"
 
-void GPUABenchmark::BufferSet::cleanup() {
+void gab::IoBuffers::cleanup() {
     // drain the device before memory it may still be using goes away
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess)

@@ -27,72 +27,85 @@
 #include "bench_utils.hpp"
 #include "globals.hpp"
 
-class GPUABenchmark {
+namespace gab {
+
+// What a run returns (bench_base.cuh:20-34) and what validate() fills in (:36-47).  Defined at
+// namespace scope and re-exported from the class under the reference's nested names.
+struct RunResult {
+    std::vector<float> latencies;          // wall ms per iteration (copies included)
+    std::vector<float> gpu_latencies;      // device ms per iteration, when recorded
+    BenchmarkUtils::Statistics statistics;
+    BenchmarkUtils::Statistics gpu_statistics;
+    std::string benchmark_name;
+    size_t buffer_size;
+    size_t track_count;
+    int iterations;
+    double throughput_gbps;                // bytes_processed / mean latency, GiB/s
+    double samples_per_sec;
+    size_t bytes_processed;
+    float mean_latency_ms;
+    // DAW pacing of this run (additive; zero when no simulator was set)
+    unsigned long long daw_waits = 0;
+    unsigned long long daw_missed_slots = 0;
+};
+
+enum class ValidationOutcome { SUCCESS = 0, FAILURE = 1, FATAL = -1 };
+
+struct ValidationReport {
+    ValidationOutcome status = ValidationOutcome::SUCCESS;
+    std::vector<std::string> messages;
+    float max_error = 0.0f;
+    float mean_error = 0.0f;
+};
+
+// Two pinned host buffers and two device buffers of element_count floats (bench_base.cuh:50-74).
+struct IoBuffers {
+    float* h_input = nullptr;
+    float* h_output = nullptr;
+    float* d_input = nullptr;
+    float* d_output = nullptr;
+    size_t element_count = 0;
+    size_t size_bytes = 0;
+
+    ~IoBuffers() { cleanup(); }
+    void cleanup();
+};
+
+}  // namespace gab
+
+// The four stages every benchmark supplies (bench_base.cuh:94-97), as an interface of their own so
+// that tooling can drive a benchmark without knowing the harness around it.
+struct BenchmarkStages {
+    virtual ~BenchmarkStages() = default;
+    virtual void setupBenchmark() = 0;                                // allocate, generate inputs, goldens
+    virtual void runKernel() = 0;                                     // device work only
+    virtual void performBenchmarkIteration() = 0;                     // H2D + device work + D2H
+    virtual void validate(gab::ValidationReport& validation_data) = 0;
+};
+
+class GPUABenchmark : public BenchmarkStages {
 public:
-    struct BenchmarkResult {
-        std::vector<float> latencies;          // wall ms per iteration (copies included)
-        std::vector<float> gpu_latencies;      // device ms per iteration, when recorded
-        BenchmarkUtils::Statistics statistics;
-        BenchmarkUtils::Statistics gpu_statistics;
-        std::string benchmark_name;
-        size_t buffer_size;
-        size_t track_count;
-        int iterations;
-        double throughput_gbps;                // bytes_processed / mean latency, GiB/s
-        double samples_per_sec;
-        size_t bytes_processed;
-        float mean_latency_ms;
-        // DAW pacing of this run (additive; zero when no simulator was set)
-        unsigned long long daw_waits = 0;
-        unsigned long long daw_missed_slots = 0;
-    };
+    // the reference's nested names
+    using BenchmarkResult = gab::RunResult;
+    using ValidationStatus = gab::ValidationOutcome;
+    using ValidationData = gab::ValidationReport;
 
-    enum class ValidationStatus { SUCCESS = 0, FAILURE = 1, FATAL = -1 };
-
-    struct ValidationData {
-        ValidationStatus status = ValidationStatus::SUCCESS;
-        std::vector<std::string> messages;
-        float max_error = 0.0f;
-        float mean_error = 0.0f;
-    };
-
-protected:
-    // Two pinned host buffers and two device buffers of element_count floats.
-    struct BufferSet {
-        float* h_input = nullptr;
-        float* h_output = nullptr;
-        float* d_input = nullptr;
-        float* d_output = nullptr;
-        size_t element_count = 0;
-        size_t size_bytes = 0;
-
-        ~BufferSet() { cleanup(); }
-        void cleanup();
-    };
-
-    BufferSet buffers;
-    BenchmarkUtils::BenchmarkTimer timer;
-    std::string benchmark_name_;
-    size_t buffer_size_;
-    size_t track_count_;
-    float current_iteration_gpu_ms_ = 0.0f;
-    hipStream_t stream_ = nullptr;             // all of this benchmark's device work
-    BenchmarkUtils::DAWSimulator daw_simulator_;
-    bool daw_enabled_ = false;
-
-public:
     GPUABenchmark(const std::string& name, size_t buffer_size = BUFSIZE, size_t track_count = NTRACKS);
-    virtual ~GPUABenchmark();
+    ~GPUABenchmark() override;
     GPUABenchmark(const GPUABenchmark&) = delete;
     GPUABenchmark& operator=(const GPUABenchmark&) = delete;
 
-    // ---- what a benchmark implements (bench_base.cuh:94-97) -----------------
-    virtual void setupBenchmark() = 0;
-    virtual void runKernel() = 0;
-    virtual void performBenchmarkIteration() = 0;
-    virtual void validate(ValidationData& validation_data) = 0;
+    // ---- the harness (bench_base.cuh:103-110) ---------------------------------------------------
+    BenchmarkResult runBenchmark(int iterations = NRUNS, int warmupIterations = 3);        // whole iterations
+    BenchmarkResult runKernelBenchmark(int iterations = NRUNS, int warmupIterations = 3);  // runKernel() only
+    void allocateBuffers(size_t element_count);
+    void generateTestData(unsigned int seed = 42);
+    void transferToDevice();
+    void transferToHost();
+    void printResults(const BenchmarkResult& result);
+    void writeResults(const BenchmarkResult& result, const std::string& filename = "");
 
-    // ---- additive hooks --------------------------------------------------------
+    // ---- additive hooks -------------------------------------------------------------------------
     virtual void resetState() {}
     virtual void runValidationIteration() { resetState(); performBenchmarkIteration(); }
     virtual size_t algorithmicBytes() const { return 2 * getTotalElements() * sizeof(float); }
@@ -104,42 +117,43 @@ public:
     bool hasDawSimulator() const { return daw_enabled_; }
     const BenchmarkUtils::DAWSimulator& dawSimulator() const { return daw_simulator_; }
 
-    // ---- provided (bench_base.cuh:103-110) -----------------------------------------
-    void allocateBuffers(size_t element_count);
-    void transferToDevice();
-    void transferToHost();
-    BenchmarkResult runKernelBenchmark(int iterations = NRUNS, int warmupIterations = 3);
-    BenchmarkResult runBenchmark(int iterations = NRUNS, int warmupIterations = 3);
-    void generateTestData(unsigned int seed = 42);
-    void writeResults(const BenchmarkResult& result, const std::string& filename = "");
-    void printResults(const BenchmarkResult& result);
-
+    // ---- identity and shape (bench_base.cuh:116-119) --------------------------------------------
     const std::string& getName() const { return benchmark_name_; }
     size_t getBufferSize() const { return buffer_size_; }
     size_t getTrackCount() const { return track_count_; }
     size_t getTotalElements() const { return buffer_size_ * track_count_; }
     hipStream_t getStream() const { return stream_; }
-
-    // read-only views for tests and bindings
-    const float* hostInput() const { return buffers.h_input; }
+    const float* hostInput() const { return buffers.h_input; }      // read-only views for tests and bindings
     const float* hostOutput() const { return buffers.h_output; }
 
 protected:
+    using BufferSet = gab::IoBuffers;
+
+    // ---- helpers for subclasses (bench_base.cuh:126-138) ----------------------------------------
+    BenchmarkResult runWithIteration(int iterations, int warmupIterations, const std::function<void()>& iterationBody);
+    ValidationData compareWithReference(const float* cpu_reference, float tolerance = 1e-5f);
+    BenchmarkUtils::BenchmarkParams makeBenchmarkParams(float gainValue = 0.0f) const;
+    std::pair<int, int> calculateGridDimensions(int desired_threads_per_block = 256) const;
+    void synchronizeAndCheck();
+    void resetGpuIterationMetrics();
+    void recordGpuDuration(float milliseconds);
     float* getHostInput() { return buffers.h_input; }
     float* getHostOutput() { return buffers.h_output; }
     float* getDeviceInput() { return buffers.d_input; }
     float* getDeviceOutput() { return buffers.d_output; }
-    BenchmarkUtils::BenchmarkParams makeBenchmarkParams(float gainValue = 0.0f) const;
-    std::pair<int, int> calculateGridDimensions(int desired_threads_per_block = 256) const;
-    void synchronizeAndCheck();
-    ValidationData compareWithReference(const float* cpu_reference, float tolerance = 1e-5f);
-    void resetGpuIterationMetrics();
-    void recordGpuDuration(float milliseconds);
-    BenchmarkResult runWithIteration(int iterations, int warmupIterations,
-                                     const std::function<void()>& iterationBody);
-
     // compare any pair of host arrays with the same bookkeeping as compareWithReference
     static ValidationData compareArrays(const float* got, const float* expected, size_t n, float tolerance);
     // throws std::runtime_error carrying gab_last_error() when a C-ABI call fails
     static void checkGab(int rc, const char* what);
+
+    // ---- state ----------------------------------------------------------------------------------
+    BufferSet buffers;
+    BenchmarkUtils::BenchmarkTimer timer;
+    std::string benchmark_name_;
+    size_t buffer_size_;
+    size_t track_count_;
+    float current_iteration_gpu_ms_ = 0.0f;
+    hipStream_t stream_ = nullptr;             // all of this benchmark's device work
+    BenchmarkUtils::DAWSimulator daw_simulator_;
+    bool daw_enabled_ = false;
 };
