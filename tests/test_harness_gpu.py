@@ -112,15 +112,17 @@ def test_dawsim_paces_the_harness_loop(gab):
     r = b.run(iterations=20, warmup=3)
     elapsed = time.perf_counter() - t0
     waits, missed = b.dawsim_stats()
-    assert waits == 23 and missed <= 1
-    assert 23 * slot - 1e-4 <= elapsed < 23 * slot + 0.25
+    assert waits == 23 and missed <= 4                  # a descheduled host may overrun a slot or two
+    assert 23 * slot - 1e-4 <= elapsed < 23 * slot + 0.5
     assert r.median_ms < slot * 1e3                     # latencies exclude the wait
     v, _ = b.validate()
     assert v.status == 0
     b.set_dawsim(enable=False)
     t0 = time.perf_counter()
     b.run(iterations=20, warmup=3)
-    assert time.perf_counter() - t0 < 23 * slot         # unpaced again
+    unpaced = time.perf_counter() - t0
+    w2, _ = b.dawsim_stats()
+    assert w2 == 0 and unpaced < elapsed                # unpaced again: no slots were waited for
     b.close()
 
 
