@@ -24,6 +24,9 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-ffp-contract=off", "-f
          "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
+if os.environ.get("GAB_EXTRA_FLAGS"):  # experiments, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp"
+    FLAGS += os.environ["GAB_EXTRA_FLAGS"].split()
+
 if os.environ.get("GAB_ABLATE"):      # diagnostic build: stage-ablation variants of the conv kernel
     FLAGS.append("-DGAB_ABLATE")
 
