@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o fdtd128 -- python3 tools/fdtd_loop.py 128 334 128 > $OUT/fdtd128.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o modal -- python3 tools/modal_loop.py > $OUT/modal.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o batch -- python3 tools/batch_conv.py 1024 > $OUT/batch.txt 2>&1
 echo "traces done"
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   N=$(echo $C | tr ' ' '_')
