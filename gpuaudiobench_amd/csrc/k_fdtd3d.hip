@@ -211,6 +211,117 @@ __global__ __launch_bounds__(256) void fdtd_step_vec4_kernel(Fields o, Fields n,
     st4(n.p + pi, pv[0], pv[1], pv[2], pv[3]);
 }
 
+// The same step with the in-plane neighbours staged through LDS: a workgroup covers ROWS rows
+// of one z-plane over the whole x extent (nx <= 4 * LX); every thread parks its own pressure and
+// vy row segment in LDS, threads of the first / last row add the halo rows above and below, and
+// p(x +/- 1), p(y +/- 1), vy(y + 1) then come from LDS instead of five more global loads.  Same
+// arithmetic, same bits.
+template <int LX, int ROWS>
+__global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fields n, Grid g, float c1,
+                                                                 float c2, float damp, size_t src, size_t rcv,
+                                                                 const float* __restrict__ add_next,
+                                                                 float* __restrict__ strip_out) {
+    constexpr int W = 4 * LX + 8;                      // row pitch in LDS: 4 floats of margin each side
+    __shared__ float sp[(ROWS + 2) * W];               // pressure rows y0-1 .. y0+ROWS
+    __shared__ float svy[(ROWS + 1) * W];              // vy rows y0 .. y0+ROWS
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int y0 = blockIdx.y * ROWS, y = y0 + ty, z = blockIdx.z;
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const int x0 = 4 * tx;
+    const bool live = x0 < nx && y < ny;
+    const size_t sxy = (size_t)nx * ny;
+    const size_t pi = z * sxy + (size_t)y * nx + x0;
+    const size_t ix = ((size_t)z * ny + y) * g.px + x0;
+    const size_t iy = ((size_t)z * (ny + 1) + y) * nx + x0;
+    const size_t iz = pi;
+    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+    auto st4 = [](float* p, float a, float b, float c, float d) {
+        *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+    };
+    auto lds4 = [](float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; };
+    float* const prow = sp + (ty + 1) * W + 4 + x0;
+    float* const vrow = svy + ty * W + 4 + x0;
+
+    float4 pc4 = make_float4(0.f, 0.f, 0.f, 0.f), vy4 = pc4, vx4 = pc4, vz4 = pc4;
+    if (live) {
+        pc4 = ld4(o.p + pi);
+        vy4 = ld4(o.vy + iy);
+        vx4 = ld4(o.vx + ix);
+        vz4 = ld4(o.vz + iz);
+        lds4(prow, pc4);
+        lds4(vrow, vy4);
+        if (ty == 0 && y > 0) lds4(prow - W, ld4(o.p + pi - nx));                          // row y0-1
+        const bool last_row = ty == ROWS - 1 || y == ny - 1;
+        if (last_row) {
+            lds4(vrow + W, ld4(o.vy + iy + nx));                                           // vy face y+1 (exists up to ny)
+            if (y < ny - 1) lds4(prow + W, ld4(o.p + pi + nx));                            // row y+1
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    const float pc[4] = {pc4.x, pc4.y, pc4.z, pc4.w};
+    float fx[5] = {vx4.x, vx4.y, vx4.z, vx4.w, o.vx[ix + 4]};
+    float fy[4] = {vy4.x, vy4.y, vy4.z, vy4.w};
+    float fz[4] = {vz4.x, vz4.y, vz4.z, vz4.w};
+    if (x0 > 0) fx[0] = __builtin_fmaf(-c1, __fsub_rn(pc[0], prow[-1]), fx[0]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) fx[j] = __builtin_fmaf(-c1, __fsub_rn(pc[j], pc[j - 1]), fx[j]);
+    const bool has_right = x0 + 4 < nx;
+    const float pr = has_right ? prow[4] : 0.0f;
+    const float fx4_new = has_right ? __builtin_fmaf(-c1, __fsub_rn(pr, pc[3]), fx[4]) : fx[4];
+    if (y > 0) {
+        const float4 q = *reinterpret_cast<const float4*>(prow - W);
+        const float pm[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fy[j] = __builtin_fmaf(-c1, __fsub_rn(pc[j], pm[j]), fy[j]);
+    }
+    if (z > 0) {
+        const float4 q = ld4(o.p + pi - sxy);
+        const float pm[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fz[j] = __builtin_fmaf(-c1, __fsub_rn(pc[j], pm[j]), fz[j]);
+    }
+    st4(n.vx + ix, fx[0], fx[1], fx[2], fx[3]);
+    st4(n.vy + iy, fy[0], fy[1], fy[2], fy[3]);
+    st4(n.vz + iz, fz[0], fz[1], fz[2], fz[3]);
+    if (!has_right) n.vx[ix + 4] = fx[4];
+    if (y == ny - 1) *reinterpret_cast<float4*>(n.vy + iy + nx) = *reinterpret_cast<const float4*>(vrow + W);
+    if (z == nz - 1) *reinterpret_cast<float4*>(n.vz + iz + sxy) = ld4(o.vz + iz + sxy);
+
+    float pv[4];
+    const bool row_interior = y > 0 && y < ny - 1 && z > 0 && z < nz - 1;
+    if (row_interior) {
+        const float4 pyp = *reinterpret_cast<const float4*>(prow + W), pzp = ld4(o.p + pi + sxy);
+        const float4 vyp = *reinterpret_cast<const float4*>(vrow + W), vzp = ld4(o.vz + iz + sxy);
+        const float py[4] = {pyp.x, pyp.y, pyp.z, pyp.w}, pz[4] = {pzp.x, pzp.y, pzp.z, pzp.w};
+        const float hyo[4] = {vyp.x, vyp.y, vyp.z, vyp.w}, hzo[4] = {vzp.x, vzp.y, vzp.z, vzp.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            if (x > 0 && x < nx - 1) {
+                const float hx = (j < 3) ? fx[j + 1] : fx4_new;
+                const float hy = __builtin_fmaf(-c1, __fsub_rn(py[j], pc[j]), hyo[j]);
+                const float hz = __builtin_fmaf(-c1, __fsub_rn(pz[j], pc[j]), hzo[j]);
+                const float div = __fadd_rn(__fadd_rn(__fsub_rn(hx, fx[j]), __fsub_rn(hy, fy[j])),
+                                            __fsub_rn(hz, fz[j]));
+                pv[j] = __builtin_fmaf(-c2, div, pc[j]);
+            } else {
+                pv[j] = __fmul_rn(pc[j], damp);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = __fmul_rn(pc[j], damp);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (strip_out != nullptr && pi + j == rcv) *strip_out = __fmul_rn(pv[j], 0.1f);
+        if (add_next != nullptr && pi + j == src) pv[j] = __fadd_rn(pv[j], *add_next);
+    }
+    st4(n.p + pi, pv[0], pv[1], pv[2], pv[3]);
+}
+
 }  // namespace
 }  // namespace gab
 
@@ -234,6 +345,7 @@ struct gab_fdtd_plan {
     int strip_cap = 0;
     size_t np = 0, nvx = 0, nvy = 0, nvz = 0;
     bool use_graphs = true;
+    bool lds_tiles = true;    // rows wide enough to fill a 32-lane row of the LDS-halo kernel (GAB_FDTD_LDS=0: off)
     hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
     std::vector<std::pair<FdtdGraphKey, hipGraphExec_t>> graphs;   // small LRU, newest last
 };
@@ -297,6 +409,7 @@ int gab_fdtd_create(gab_fdtd_plan** out, const gab_fdtd_params* params) {
         auto* f = new gab_fdtd_plan;
         f->P = P;
         if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
+        if (const char* v = getenv("GAB_FDTD_LDS")) f->lds_tiles = atoi(v) != 0;
         f->np = (size_t)P.nx * P.ny * P.nz;
         f->nvx = (size_t)(P.nx + 4) * P.ny * P.nz + 4;   // padded pitch, see file header
         f->nvy = (size_t)P.nx * (P.ny + 1) * P.nz;
@@ -384,7 +497,16 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
                     const bool closes = step == P.steps_per_sample - 1;
                     const float* add_next = (closes && smp + 1 < last) ? f->inj + smp + 1 : nullptr;
                     float* strip_out = closes ? f->strip + smp : nullptr;
-                    if (vec4)
+                    if (vec4 && f->lds_tiles && tx > 16 && tx <= 64) {
+                        // whole x extent in one workgroup: LX x ROWS = 256 threads, (ROWS + 2) pressure
+                        // rows in LDS; LX is the smallest of 16 / 32 / 64 that covers nx / 4
+#define GAB_FDTD_LDS_LAUNCH(LX, ROWS)                                                                 \
+    gab::fdtd_step_lds_kernel<LX, ROWS><<<dim3(1, (P.ny + ROWS - 1) / ROWS, P.nz), dim3(LX, ROWS, 1), 0, q>>>( \
+        cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out)
+                        if (tx <= 32) GAB_FDTD_LDS_LAUNCH(32, 8);
+                        else GAB_FDTD_LDS_LAUNCH(64, 4);
+#undef GAB_FDTD_LDS_LAUNCH
+                    } else if (vec4)
                         gab::fdtd_step_vec4_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx,
                                                                          P.rho_c2_dt_over_dx, damp, src, rcv,
                                                                          add_next, strip_out);
