@@ -457,7 +457,9 @@ def test_dwg_audible_configuration(gab, orc, variant):
 
 
 @pytest.mark.parametrize("n,T,B,samples", [(20, 4, 16, 16), (52, 128, 512, 24), (33, 3, 8, 8),
-                                          (128, 16, 8, 6)])      # C4's grid, a few samples
+                                          (128, 16, 8, 6),       # C4's grid, a few samples (LDS-halo kernel, 32 x 8)
+                                          (100, 3, 6, 6),        # 32 x 8 tiles with a partial last tile row
+                                          (148, 2, 4, 4)])       # 64 x 4 tiles
 def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     import torch
     P = orc.fdtd_params(n)
