@@ -503,7 +503,14 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
 #define GAB_FDTD_LDS_LAUNCH(LX, ROWS)                                                                 \
     gab::fdtd_step_lds_kernel<LX, ROWS><<<dim3(1, (P.ny + ROWS - 1) / ROWS, P.nz), dim3(LX, ROWS, 1), 0, q>>>( \
         cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out)
-                        if (tx <= 32) GAB_FDTD_LDS_LAUNCH(32, 8);
+                        // 512-thread tiles (half as many halo rows) once they still make >= 4 workgroups
+                        // per CU; 256-thread tiles below that (measured: 13.6 vs 14.3 us/step at 128^3,
+                        // 47.5 vs 49.6 at 200^3, but 9.5 vs 8.8 at 96^3)
+                        const int lx = tx <= 32 ? 32 : 64;
+                        const bool big = (long)((P.ny + 512 / lx - 1) / (512 / lx)) * P.nz >= 1024;
+                        if (lx == 32 && big) GAB_FDTD_LDS_LAUNCH(32, 16);
+                        else if (lx == 32) GAB_FDTD_LDS_LAUNCH(32, 8);
+                        else if (big) GAB_FDTD_LDS_LAUNCH(64, 8);
                         else GAB_FDTD_LDS_LAUNCH(64, 4);
 #undef GAB_FDTD_LDS_LAUNCH
                     } else if (vec4)
