@@ -162,6 +162,14 @@ int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
  * Additive: the reference processes one buffer per iteration.                    */
 int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
                            int n_buffers, gab_stream_t stream);
+/* Stateless streaming: the history is the caller's own last eight input buffers
+ * (d_previous[0] = the buffer before d_in ... d_previous[7] = eight buffers back; same
+ * layout as d_in; a buffer of zeros stands for "before the stream began").  Nothing in
+ * the plan is read or written but the spectra, so consecutive buffers may be issued on
+ * different streams and overlap on the device.  Same results as gab_conv_process in
+ * streaming mode fed the same sequence.  Needs bufsize 512 and 512 < ir_len <= 4096.  */
+int gab_conv_process_windowed(gab_conv_plan* plan, const float* d_in,
+                              const float* const* d_previous, float* d_out, gab_stream_t stream);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
                          size_t* history_bytes);
