@@ -99,6 +99,14 @@ PROTOTYPES = {
     "gab_fdtd_reset": (_I, [_P, _P]),
     "gab_fdtd_process": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "gab_fdtd_copy_pressure": (_I, [_P, _P, _P]),
+    "gab_fdtd_create_slab": (_I, [C.POINTER(_P), C.POINTER(FdtdParams), _I, _I]),
+    "gab_fdtd_owns": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "gab_fdtd_source_sums": (_I, [_P, _P, _I, _I, _P]),
+    "gab_fdtd_inject": (_I, [_P, _I, _P]),
+    "gab_fdtd_step": (_I, [_P, _I, _P]),
+    "gab_fdtd_halo": (_I, [_P, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "gab_fdtd_emit": (_I, [_P, _P, _I, _I, _P]),
+    "gab_fdtd_strip": (_I, [_P, C.POINTER(_P), C.POINTER(_I)]),
     "gab_generate_noise": (_I, [_P, _Z, C.c_uint]),
     "gab_generate_conv1d_ir": (_I, [_P, _I, _Z, _Z, _Z]),
     "gab_generate_conv_accel_ir": (_I, [_P, _I, _Z, _Z, _Z]),

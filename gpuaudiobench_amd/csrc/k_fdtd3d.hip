@@ -27,7 +27,9 @@
 // pressure grid, which is what a caller can read back, is unchanged).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdlib>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -36,7 +38,9 @@
 namespace gab {
 namespace {
 
-struct Grid { int nx, ny, nz, px; };   // px = pitch of a vx row (nx + 4)
+// px = pitch of a vx row (nx + 4); z0 = global z of the first plane a launch covers (a z-slab of
+// a decomposed grid launches only its own planes; nz stays the GLOBAL depth for the boundary tests)
+struct Grid { int nx, ny, nz, px, z0; };
 
 struct Fields { float *p, *vx, *vy, *vz; };
 
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void fdtd_step_kernel(Fields o, Fields n, Grid
                                                        float* __restrict__ strip_out) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int z = blockIdx.z;
+    const int z = blockIdx.z + g.z0;
     if (x >= g.nx || y >= g.ny) return;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const size_t sxy = (size_t)nx * ny;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void fdtd_step_vec4_kernel(Fields o, Fields n,
                                                             float* __restrict__ strip_out) {
     const int tx = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int z = blockIdx.z;
+    const int z = blockIdx.z + g.z0;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const int x0 = 4 * tx;
     if (x0 >= nx || y >= ny) return;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     __shared__ float sp[(ROWS + 2) * W];               // pressure rows y0-1 .. y0+ROWS
     __shared__ float svy[(ROWS + 1) * W];              // vy rows y0 .. y0+ROWS
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int y0 = blockIdx.y * ROWS, y = y0 + ty, z = blockIdx.z;
+    const int y0 = blockIdx.y * ROWS, y = y0 + ty, z = blockIdx.z + g.z0;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const int x0 = 4 * tx;
     const bool live = x0 < nx && y < ny;
@@ -343,7 +347,12 @@ struct gab_fdtd_plan {
     float* inj = nullptr;              // per-sample source sums of the current buffer
     float* strip = nullptr;            // per-sample receiver values
     int strip_cap = 0;
-    size_t np = 0, nvx = 0, nvy = 0, nvz = 0;
+    size_t np = 0, nvx = 0, nvy = 0, nvz = 0;   // floats ALLOCATED per field (slab + ghosts)
+    // z-slab of a decomposed grid: planes [z_begin, z_end) are owned; the pressure array carries one
+    // ghost plane below and above, the vz array one ghost face plane above.  cur / nxt hold VIRTUAL
+    // base pointers (real base minus the slab's offset), so the kernels index with global z.
+    int z_begin = 0, z_end = 0;
+    gab::Fields cur_real{}, nxt_real{};
     bool use_graphs = true;
     bool lds_tiles = true;    // rows wide enough to fill a 32-lane row of the LDS-halo kernel (GAB_FDTD_LDS=0: off)
     hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
@@ -374,6 +383,115 @@ void zero_fields(gab::Fields& f, const gab_fdtd_plan& pl, hipStream_t s) {
     GAB_HIP_CHECK(hipMemsetAsync(f.vz, 0, pl.nvz * sizeof(float), s));
 }
 
+// real base -> the base the kernels index with global z (integer arithmetic: the result may lie
+// before the allocation; only planes z_begin-1 .. z_end are ever dereferenced through it)
+gab::Fields virtual_base(const gab::Fields& real, const gab_fdtd_plan& pl) {
+    const gab_fdtd_params& P = pl.P;
+    const long long sxy = (long long)P.nx * P.ny;
+    auto shift = [](float* p, long long floats) {
+        return reinterpret_cast<float*>(reinterpret_cast<intptr_t>(p) - (intptr_t)(floats * (long long)sizeof(float)));
+    };
+    gab::Fields v;
+    v.p = shift(real.p, ((long long)pl.z_begin - 1) * sxy);
+    v.vz = shift(real.vz, (long long)pl.z_begin * sxy);
+    v.vx = shift(real.vx, (long long)pl.z_begin * P.ny * (P.nx + 4));
+    v.vy = shift(real.vy, (long long)pl.z_begin * (P.ny + 1) * P.nx);
+    return v;
+}
+
+int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin, int z_end, const char* who) {
+    if (!out || !params) return gab::bad_arg((std::string(who) + ": null pointer").c_str());
+    const gab_fdtd_params& P = *params;
+    if (P.nx < 3 || P.ny < 3 || P.nz < 3) return gab::bad_arg((std::string(who) + ": grid too small").c_str());
+    auto inside = [&](int x, int y, int z) {
+        return x >= 0 && x < P.nx && y >= 0 && y < P.ny && z >= 0 && z < P.nz;
+    };
+    if (!inside(P.source_x, P.source_y, P.source_z) || !inside(P.receiver_x, P.receiver_y, P.receiver_z))
+        return gab::bad_arg((std::string(who) + ": source/receiver outside the grid").c_str());
+    if (P.steps_per_sample < 1) return gab::bad_arg((std::string(who) + ": steps_per_sample must be >= 1").c_str());
+    if (z_begin < 0 || z_end > P.nz || z_end - z_begin < 1)
+        return gab::bad_arg((std::string(who) + ": slab must be a non-empty range inside [0, nz)").c_str());
+    auto* f = new gab_fdtd_plan;
+    f->P = P;
+    f->z_begin = z_begin;
+    f->z_end = z_end;
+    if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
+    if (const char* v = getenv("GAB_FDTD_LDS")) f->lds_tiles = atoi(v) != 0;
+    const size_t nzl = (size_t)(z_end - z_begin);
+    f->np = (size_t)P.nx * P.ny * (nzl + 2);
+    f->nvx = (size_t)(P.nx + 4) * P.ny * nzl + 4;    // padded pitch, see file header
+    f->nvy = (size_t)P.nx * (P.ny + 1) * nzl;
+    f->nvz = (size_t)P.nx * P.ny * (nzl + 1);
+    try {
+        alloc_fields(f->cur_real, *f);
+        alloc_fields(f->nxt_real, *f);
+    } catch (...) {
+        gab_fdtd_destroy(f);
+        throw;
+    }
+    f->cur = virtual_base(f->cur_real, *f);
+    f->nxt = virtual_base(f->nxt_real, *f);
+    *out = f;
+    int rc = gab_fdtd_reset(f, nullptr);
+    if (rc) return rc;
+    GAB_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return GAB_OK;
+}
+
+// One leapfrog step old -> new over the plan's own planes, with the kernel form that suits the row
+// width (see the kernels above).
+void launch_step(const gab_fdtd_plan* f, hipStream_t q, const gab::Fields& cur, const gab::Fields& nxt,
+                 const float* add_next, float* strip_out) {
+    const gab_fdtd_params& P = f->P;
+    const int nzl = f->z_end - f->z_begin;
+    gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, f->z_begin};
+    const size_t sxy = (size_t)P.nx * P.ny;
+    const size_t src = P.source_z * sxy + (size_t)P.source_y * P.nx + P.source_x;
+    const size_t rcv = P.receiver_z * sxy + (size_t)P.receiver_y * P.nx + P.receiver_x;
+    const float damp = 1.0f - P.absorption_coeff;
+    const bool vec4 = (P.nx % 4) == 0;
+    const int tx = vec4 ? P.nx / 4 : P.nx;                    // threads along x
+    const int bx = tx >= 64 ? 64 : (tx >= 32 ? 32 : 16);
+    dim3 block(bx, 256 / bx, 1);
+    dim3 grid((tx + bx - 1) / bx, (P.ny + block.y - 1) / block.y, nzl);
+    if (vec4 && f->lds_tiles && tx > 16 && tx <= 64) {
+        // whole x extent in one workgroup: LX x ROWS threads, (ROWS + 2) pressure rows in LDS
+#define GAB_FDTD_LDS_LAUNCH(LX, ROWS)                                                                 \
+    gab::fdtd_step_lds_kernel<LX, ROWS><<<dim3(1, (P.ny + ROWS - 1) / ROWS, nzl), dim3(LX, ROWS, 1), 0, q>>>( \
+        cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out)
+        // 512-thread tiles (half as many halo rows) once they still make >= 4 workgroups
+        // per CU; 256-thread tiles below that (measured: 13.6 vs 14.3 us/step at 128^3,
+        // 47.5 vs 49.6 at 200^3, but 9.5 vs 8.8 at 96^3)
+        const int lx = tx <= 32 ? 32 : 64;
+        const bool big = (long)((P.ny + 512 / lx - 1) / (512 / lx)) * nzl >= 1024;
+        if (lx == 32 && big) GAB_FDTD_LDS_LAUNCH(32, 16);
+        else if (lx == 32) GAB_FDTD_LDS_LAUNCH(32, 8);
+        else if (big) GAB_FDTD_LDS_LAUNCH(64, 8);
+        else GAB_FDTD_LDS_LAUNCH(64, 4);
+#undef GAB_FDTD_LDS_LAUNCH
+    } else if (vec4) {
+        gab::fdtd_step_vec4_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp,
+                                                         src, rcv, add_next, strip_out);
+    } else {
+        gab::fdtd_step_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src,
+                                                    rcv, add_next, strip_out);
+    }
+}
+
+void ensure_strips(gab_fdtd_plan* f, int bufsize, hipStream_t s) {
+    if (f->strip_cap >= bufsize) return;
+    GAB_HIP_CHECK(hipStreamSynchronize(s));
+    for (auto& c : f->graphs) (void)hipGraphExecDestroy(c.second);   // they point at the old strips
+    f->graphs.clear();
+    if (f->inj) (void)hipFree(f->inj);
+    if (f->strip) (void)hipFree(f->strip);
+    f->inj = f->strip = nullptr;
+    GAB_HIP_CHECK(hipMalloc(&f->inj, sizeof(float) * bufsize));
+    GAB_HIP_CHECK(hipMalloc(&f->strip, sizeof(float) * bufsize));
+    GAB_HIP_CHECK(hipMemsetAsync(f->strip, 0, sizeof(float) * bufsize, s));
+    f->strip_cap = bufsize;
+}
+
 }  // namespace
 
 extern "C" {
@@ -397,36 +515,12 @@ int gab_fdtd_default_params(int nx, int ny, int nz, gab_fdtd_params* out) {
 
 int gab_fdtd_create(gab_fdtd_plan** out, const gab_fdtd_params* params) {
     return gab::guarded([&]() -> int {
-        if (!out || !params) return gab::bad_arg("gab_fdtd_create: null pointer");
-        const gab_fdtd_params& P = *params;
-        if (P.nx < 3 || P.ny < 3 || P.nz < 3) return gab::bad_arg("gab_fdtd_create: grid too small");
-        auto inside = [&](int x, int y, int z) {
-            return x >= 0 && x < P.nx && y >= 0 && y < P.ny && z >= 0 && z < P.nz;
-        };
-        if (!inside(P.source_x, P.source_y, P.source_z) || !inside(P.receiver_x, P.receiver_y, P.receiver_z))
-            return gab::bad_arg("gab_fdtd_create: source/receiver outside the grid");
-        if (P.steps_per_sample < 1) return gab::bad_arg("gab_fdtd_create: steps_per_sample must be >= 1");
-        auto* f = new gab_fdtd_plan;
-        f->P = P;
-        if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
-        if (const char* v = getenv("GAB_FDTD_LDS")) f->lds_tiles = atoi(v) != 0;
-        f->np = (size_t)P.nx * P.ny * P.nz;
-        f->nvx = (size_t)(P.nx + 4) * P.ny * P.nz + 4;   // padded pitch, see file header
-        f->nvy = (size_t)P.nx * (P.ny + 1) * P.nz;
-        f->nvz = (size_t)P.nx * P.ny * (P.nz + 1);
-        try {
-            alloc_fields(f->cur, *f);
-            alloc_fields(f->nxt, *f);
-        } catch (...) {
-            gab_fdtd_destroy(f);
-            throw;
-        }
-        *out = f;
-        int rc = gab_fdtd_reset(f, nullptr);
-        if (rc) return rc;
-        GAB_HIP_CHECK(hipStreamSynchronize(nullptr));
-        return GAB_OK;
+        return create_slab(out, params, 0, params ? params->nz : 0, "gab_fdtd_create");
     });
+}
+
+int gab_fdtd_create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin, int z_end) {
+    return gab::guarded([&]() -> int { return create_slab(out, params, z_begin, z_end, "gab_fdtd_create_slab"); });
 }
 
 int gab_fdtd_destroy(gab_fdtd_plan* f) {
@@ -434,8 +528,8 @@ int gab_fdtd_destroy(gab_fdtd_plan* f) {
     (void)hipDeviceSynchronize();
     for (auto& g : f->graphs) (void)hipGraphExecDestroy(g.second);
     if (f->capture_stream) (void)hipStreamDestroy(f->capture_stream);
-    free_fields(f->cur);
-    free_fields(f->nxt);
+    free_fields(f->cur_real);
+    free_fields(f->nxt_real);
     if (f->inj) (void)hipFree(f->inj);
     if (f->strip) (void)hipFree(f->strip);
     delete f;
@@ -446,8 +540,8 @@ int gab_fdtd_reset(gab_fdtd_plan* f, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!f) return gab::bad_arg("gab_fdtd_reset: null plan");
         hipStream_t s = gab::as_stream(stream);
-        zero_fields(f->cur, *f, s);
-        zero_fields(f->nxt, *f, s);
+        zero_fields(f->cur_real, *f, s);
+        zero_fields(f->nxt_real, *f, s);
         return GAB_OK;
     });
 }
@@ -461,23 +555,12 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             return gab::bad_arg("gab_fdtd_process: sample range outside the buffer");
         if (n_samples == 0) return GAB_OK;
         const gab_fdtd_params& P = f->P;
+        if (f->z_begin != 0 || f->z_end != P.nz)
+            return gab::bad_arg("gab_fdtd_process: a z-slab is stepped with gab_fdtd_step (halo exchange between steps)");
         hipStream_t s = gab::as_stream(stream);
-        if (f->strip_cap < bufsize) {
-            GAB_HIP_CHECK(hipStreamSynchronize(s));
-            for (auto& c : f->graphs) (void)hipGraphExecDestroy(c.second);   // they point at the old strips
-            f->graphs.clear();
-            if (f->inj) (void)hipFree(f->inj);
-            if (f->strip) (void)hipFree(f->strip);
-            f->inj = f->strip = nullptr;
-            GAB_HIP_CHECK(hipMalloc(&f->inj, sizeof(float) * bufsize));
-            GAB_HIP_CHECK(hipMalloc(&f->strip, sizeof(float) * bufsize));
-            f->strip_cap = bufsize;
-        }
-        gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4};
+        ensure_strips(f, bufsize, s);
         const size_t sxy = (size_t)P.nx * P.ny;
         const size_t src = P.source_z * sxy + (size_t)P.source_y * P.nx + P.source_x;
-        const size_t rcv = P.receiver_z * sxy + (size_t)P.receiver_y * P.nx + P.receiver_x;
-        const float damp = 1.0f - P.absorption_coeff;
         const int last = first_sample + n_samples;
 
         // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
@@ -487,40 +570,12 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             // the first sample's source goes straight into the current pressure grid; later
             // ones are folded into the step that precedes them
             gab::fdtd_add_source_kernel<<<1, 64, 0, q>>>(cur.p, src, f->inj, first_sample);
-            const bool vec4 = (P.nx % 4) == 0;
-            const int tx = vec4 ? P.nx / 4 : P.nx;                    // threads along x
-            const int bx = tx >= 64 ? 64 : (tx >= 32 ? 32 : 16);
-            dim3 block(bx, 256 / bx, 1);
-            dim3 grid((tx + bx - 1) / bx, (P.ny + block.y - 1) / block.y, P.nz);
             for (int smp = first_sample; smp < last; ++smp) {
                 for (int step = 0; step < P.steps_per_sample; ++step) {
                     const bool closes = step == P.steps_per_sample - 1;
                     const float* add_next = (closes && smp + 1 < last) ? f->inj + smp + 1 : nullptr;
                     float* strip_out = closes ? f->strip + smp : nullptr;
-                    if (vec4 && f->lds_tiles && tx > 16 && tx <= 64) {
-                        // whole x extent in one workgroup: LX x ROWS = 256 threads, (ROWS + 2) pressure
-                        // rows in LDS; LX is the smallest of 16 / 32 / 64 that covers nx / 4
-#define GAB_FDTD_LDS_LAUNCH(LX, ROWS)                                                                 \
-    gab::fdtd_step_lds_kernel<LX, ROWS><<<dim3(1, (P.ny + ROWS - 1) / ROWS, P.nz), dim3(LX, ROWS, 1), 0, q>>>( \
-        cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out)
-                        // 512-thread tiles (half as many halo rows) once they still make >= 4 workgroups
-                        // per CU; 256-thread tiles below that (measured: 13.6 vs 14.3 us/step at 128^3,
-                        // 47.5 vs 49.6 at 200^3, but 9.5 vs 8.8 at 96^3)
-                        const int lx = tx <= 32 ? 32 : 64;
-                        const bool big = (long)((P.ny + 512 / lx - 1) / (512 / lx)) * P.nz >= 1024;
-                        if (lx == 32 && big) GAB_FDTD_LDS_LAUNCH(32, 16);
-                        else if (lx == 32) GAB_FDTD_LDS_LAUNCH(32, 8);
-                        else if (big) GAB_FDTD_LDS_LAUNCH(64, 8);
-                        else GAB_FDTD_LDS_LAUNCH(64, 4);
-#undef GAB_FDTD_LDS_LAUNCH
-                    } else if (vec4)
-                        gab::fdtd_step_vec4_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx,
-                                                                         P.rho_c2_dt_over_dx, damp, src, rcv,
-                                                                         add_next, strip_out);
-                    else
-                        gab::fdtd_step_kernel<<<grid, block, 0, q>>>(cur, nxt, g, P.dt_over_rho_dx,
-                                                                    P.rho_c2_dt_over_dx, damp, src, rcv,
-                                                                    add_next, strip_out);
+                    launch_step(f, q, cur, nxt, add_next, strip_out);
                     std::swap(cur, nxt);
                 }
             }
@@ -562,16 +617,99 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             replayed = true;
         }
         if (!replayed) enqueue(s, f->cur, f->nxt);
-        if (((long)n_samples * P.steps_per_sample) & 1) std::swap(f->cur, f->nxt);
+        if (((long)n_samples * P.steps_per_sample) & 1) {
+            std::swap(f->cur, f->nxt);
+            std::swap(f->cur_real, f->nxt_real);
+        }
         return gab::launch_status("fdtd kernels");
     });
+}
+
+// ---- z-slab stepping (domain decomposition) -------------------------------------
+int gab_fdtd_owns(const gab_fdtd_plan* f, int* owns_source, int* owns_receiver) {
+    if (!f) return gab::bad_arg("gab_fdtd_owns: null plan");
+    if (owns_source) *owns_source = f->P.source_z >= f->z_begin && f->P.source_z < f->z_end;
+    if (owns_receiver) *owns_receiver = f->P.receiver_z >= f->z_begin && f->P.receiver_z < f->z_end;
+    return GAB_OK;
+}
+
+int gab_fdtd_source_sums(gab_fdtd_plan* f, const float* d_in, int tracks, int bufsize, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!f || !d_in) return gab::bad_arg("gab_fdtd_source_sums: null pointer");
+        if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_fdtd_source_sums: sizes must be > 0");
+        hipStream_t s = gab::as_stream(stream);
+        ensure_strips(f, bufsize, s);
+        gab::fdtd_source_sums_kernel<<<(bufsize + 127) / 128, 128, 0, s>>>(d_in, f->inj, tracks, bufsize, 0, bufsize);
+        return gab::launch_status("fdtd_source_sums_kernel");
+    });
+}
+
+int gab_fdtd_inject(gab_fdtd_plan* f, int sample, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!f) return gab::bad_arg("gab_fdtd_inject: null plan");
+        if (sample < 0 || sample >= f->strip_cap) return gab::bad_arg("gab_fdtd_inject: call gab_fdtd_source_sums first");
+        const gab_fdtd_params& P = f->P;
+        if (P.source_z < f->z_begin || P.source_z >= f->z_end) return GAB_OK;       // another slab's cell
+        const size_t sxy = (size_t)P.nx * P.ny;
+        const size_t src = P.source_z * sxy + (size_t)P.source_y * P.nx + P.source_x;
+        gab::fdtd_add_source_kernel<<<1, 64, 0, gab::as_stream(stream)>>>(f->cur.p, src, f->inj, sample);
+        return gab::launch_status("fdtd_add_source_kernel");
+    });
+}
+
+int gab_fdtd_step(gab_fdtd_plan* f, int strip_sample, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!f) return gab::bad_arg("gab_fdtd_step: null plan");
+        if (strip_sample >= f->strip_cap) return gab::bad_arg("gab_fdtd_step: strip_sample outside the buffer");
+        float* strip_out = strip_sample >= 0 ? f->strip + strip_sample : nullptr;
+        launch_step(f, gab::as_stream(stream), f->cur, f->nxt, nullptr, strip_out);
+        std::swap(f->cur, f->nxt);
+        std::swap(f->cur_real, f->nxt_real);
+        return gab::launch_status("fdtd step");
+    });
+}
+
+int gab_fdtd_halo(gab_fdtd_plan* f, int which, float** d_ptr, size_t* n_floats) {
+    if (!f || !d_ptr || !n_floats) return gab::bad_arg("gab_fdtd_halo: null pointer");
+    const size_t sxy = (size_t)f->P.nx * f->P.ny;
+    const size_t nzl = (size_t)(f->z_end - f->z_begin);
+    *n_floats = sxy;
+    switch (which) {
+        case GAB_FDTD_SEND_DOWN_P:  *d_ptr = f->cur_real.p + sxy; break;                 // plane z_begin
+        case GAB_FDTD_SEND_DOWN_VZ: *d_ptr = f->cur_real.vz; break;                       // face z_begin
+        case GAB_FDTD_SEND_UP_P:    *d_ptr = f->cur_real.p + sxy * nzl; break;            // plane z_end-1
+        case GAB_FDTD_RECV_DOWN_P:  *d_ptr = f->cur_real.p; break;                        // ghost z_begin-1
+        case GAB_FDTD_RECV_UP_P:    *d_ptr = f->cur_real.p + sxy * (nzl + 1); break;      // ghost z_end
+        case GAB_FDTD_RECV_UP_VZ:   *d_ptr = f->cur_real.vz + sxy * nzl; break;           // ghost face z_end
+        default: return gab::bad_arg("gab_fdtd_halo: unknown plane selector");
+    }
+    return GAB_OK;
+}
+
+int gab_fdtd_emit(gab_fdtd_plan* f, float* d_out, int tracks, int bufsize, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!f || !d_out) return gab::bad_arg("gab_fdtd_emit: null pointer");
+        if (tracks <= 0 || bufsize <= 0 || bufsize > f->strip_cap)
+            return gab::bad_arg("gab_fdtd_emit: sizes must be > 0 and within the recorded strip");
+        gab::fdtd_broadcast_kernel<<<dim3((bufsize + 127) / 128, tracks), 128, 0, gab::as_stream(stream)>>>(
+            f->strip, d_out, tracks, bufsize, 0, bufsize);
+        return gab::launch_status("fdtd_broadcast_kernel");
+    });
+}
+
+int gab_fdtd_strip(gab_fdtd_plan* f, float** d_strip, int* capacity) {
+    if (!f || !d_strip) return gab::bad_arg("gab_fdtd_strip: null pointer");
+    *d_strip = f->strip;
+    if (capacity) *capacity = f->strip_cap;
+    return GAB_OK;
 }
 
 int gab_fdtd_copy_pressure(gab_fdtd_plan* f, float* d_dst, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!f || !d_dst) return gab::bad_arg("gab_fdtd_copy_pressure: null pointer");
-        GAB_HIP_CHECK(hipMemcpyAsync(d_dst, f->cur.p, f->np * sizeof(float), hipMemcpyDeviceToDevice,
-                                     gab::as_stream(stream)));
+        const size_t sxy = (size_t)f->P.nx * f->P.ny;
+        GAB_HIP_CHECK(hipMemcpyAsync(d_dst, f->cur_real.p + sxy, sxy * (size_t)(f->z_end - f->z_begin) * sizeof(float),
+                                     hipMemcpyDeviceToDevice, gab::as_stream(stream)));
         return GAB_OK;
     });
 }

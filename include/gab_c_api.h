@@ -198,7 +198,34 @@ int gab_fdtd_reset(gab_fdtd_plan* plan, gab_stream_t stream);     /* zero grids 
 int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
                      int tracks, int bufsize, int first_sample, int n_samples,
                      gab_stream_t stream);
-/* Copy the current pressure grid (nx*ny*nz floats, x fastest) to d_dst.      */
+/* ---- z-slab domain decomposition (Metal comments kernels_fdtd3d.metal:184,217) ----
+ * A plan that owns planes [z_begin, z_end) of the global grid, with one ghost pressure plane below
+ * and above and one ghost vz face plane above.  One leapfrog step needs, from the slab below, its
+ * top pressure plane, and from the slab above, its bottom pressure plane and bottom vz faces:
+ *   per step:  gab_fdtd_step on every slab  ->  exchange the planes gab_fdtd_halo names
+ *   per sample: gab_fdtd_inject (owner of the source acts, others return at once), steps_per_sample
+ *   steps, the last one with strip_sample = the sample index (owner of the receiver stores
+ *   0.1 * p[receiver] into its strip).
+ * gab_fdtd_process needs the whole grid in one plan.                                              */
+int gab_fdtd_create_slab(gab_fdtd_plan** plan, const gab_fdtd_params* params, int z_begin, int z_end);
+int gab_fdtd_owns(const gab_fdtd_plan* plan, int* owns_source, int* owns_receiver);
+/* inj[s] = sum over tracks of 0.1 * in[t, s], in track order, for the whole buffer */
+int gab_fdtd_source_sums(gab_fdtd_plan* plan, const float* d_in, int tracks, int bufsize, gab_stream_t stream);
+int gab_fdtd_inject(gab_fdtd_plan* plan, int sample, gab_stream_t stream);
+int gab_fdtd_step(gab_fdtd_plan* plan, int strip_sample /* -1: none */, gab_stream_t stream);
+#define GAB_FDTD_SEND_DOWN_P  0   /* my plane z_begin      -> lower slab's GAB_FDTD_RECV_UP_P   */
+#define GAB_FDTD_SEND_DOWN_VZ 1   /* my faces z_begin      -> lower slab's GAB_FDTD_RECV_UP_VZ  */
+#define GAB_FDTD_SEND_UP_P    2   /* my plane z_end-1      -> upper slab's GAB_FDTD_RECV_DOWN_P */
+#define GAB_FDTD_RECV_DOWN_P  3
+#define GAB_FDTD_RECV_UP_P    4
+#define GAB_FDTD_RECV_UP_VZ   5
+/* device pointer and length (nx*ny floats) of a halo plane of the CURRENT fields */
+int gab_fdtd_halo(gab_fdtd_plan* plan, int which, float** d_ptr, size_t* n_floats);
+/* out[t*bufsize + s] = strip[s] for every track: the receiver's owner writes the buffer's output */
+int gab_fdtd_emit(gab_fdtd_plan* plan, float* d_out, int tracks, int bufsize, gab_stream_t stream);
+/* the per-sample receiver values this slab recorded (meaningful on the receiver's owner) */
+int gab_fdtd_strip(gab_fdtd_plan* plan, float** d_strip, int* capacity);
+/* Copy the plan's own pressure planes (nx*ny*(z_end-z_begin) floats, x fastest) to d_dst. */
 int gab_fdtd_copy_pressure(gab_fdtd_plan* plan, float* d_dst, gab_stream_t stream);
 
 /* ===================================================================== */

@@ -543,6 +543,67 @@ def test_fdtd_c4_grid_scaling_property(gab, orc):
     assert np.abs(fields[1][~normal] - 2.0 * fields[0][~normal]).max() < 1e-25
 
 
+@pytest.mark.parametrize("n,cuts,T,B", [
+    (20, [(0, 10), (10, 20)], 4, 12),                 # scalar rows; even cut
+    (52, [(0, 5), (5, 6), (6, 26), (26, 52)], 8, 10), # source plane z=5 is a one-plane slab of its own
+    (52, [(0, 25), (25, 52)], 8, 40),                 # receiver plane z=25 sits on a cut; the wave crosses it
+    (33, [(0, 1), (1, 32), (32, 33)], 3, 6),          # the two boundary planes alone; odd row length
+    (128, [(0, 40), (40, 90), (90, 128)], 4, 4),      # C4's grid, LDS-halo kernel, uneven thirds
+])
+def test_fdtd_z_slabs_reproduce_the_single_grid(gab, orc, n, cuts, T, B):
+    """any cut of the room into z-slabs with plane exchange gives the single grid's
+    output and pressure field bit for bit (and therefore the oracle's)."""
+    import torch
+    from gpuaudiobench_amd import fdtd_slabs as fs
+    G = gab.fdtd_default_params(n)
+    x = orc.Rand(3).bipolar(T * B)
+    P = orc.fdtd_params(n)
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+
+    slabs = [fs.FdtdSlab(G, a, b) for a, b in cuts]
+    assert sum(s.owns_source for s in slabs) == 1 and sum(s.owns_receiver for s in slabs) == 1
+    out = torch.zeros(T * B, device="cuda")
+    fs.process_local(slabs, dev(x), out, T, B)
+    field = torch.cat([s.pressure() for s in slabs]).cpu().numpy().ravel()
+    assert np.array_equal(bits(host(out)), bits(ref))
+    assert np.array_equal(bits(field), bits(grids[0]))
+    assert np.abs(grids[0]).max() > 0
+    if B >= 40:
+        assert np.abs(ref).max() > 0                  # the front reached the receiver through the cut
+
+    # a second buffer: slab state carries on like the plan's
+    orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+    fs.process_local(slabs, dev(x), out, T, B)
+    assert np.array_equal(bits(host(out)), bits(ref))
+    for s in slabs:
+        s.reset()
+        assert not s.pressure().any()
+        s.close()
+
+
+def test_fdtd_slab_argument_errors(gab):
+    import ctypes as C
+    import torch
+    from gpuaudiobench_amd import fdtd_slabs as fs
+    G = gab.fdtd_default_params(20)
+    for a, b in ((-1, 5), (5, 5), (7, 3), (0, 21)):
+        with pytest.raises(gab.GabError):
+            fs.FdtdSlab(G, a, b)
+    s = fs.FdtdSlab(G, 0, 10)
+    with pytest.raises(gab.GabError):
+        s.inject(0)                                   # no source sums yet
+    x = torch.zeros(16, device="cuda")
+    with pytest.raises(gab.GabError):                 # the whole-grid entry point refuses a slab
+        gab.check(gab.lib.gab_fdtd_process(s._h, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()),
+                                           2, 8, 0, 8, None))
+    assert fs.slab_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    with pytest.raises(ValueError):
+        fs.slab_ranges(3, 4)
+    s.close()
+
+
 def test_rndmem_small_pool(gab, orc):
     T, B, N = 130, 512, 1 << 20
     pool = orc.rndmem_pool(N)
