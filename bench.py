@@ -68,11 +68,19 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # GAB_BENCH_REHEARSE=1: every rank on device 0 with gloo, to walk the N>1 code path on a one-GPU
+    # box (ranks then share the device, so the rate means nothing; the line says so in `data`)
+    rehearse = os.environ.get("GAB_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import gpuaudiobench_amd as gab           # raises if libgab_hip.so is missing
 
@@ -247,7 +255,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: all ranks share device 0 over gloo",
         "config": {
             "workload": "bench_conv1d_accel streaming overlap-save: %d-tap IR x %d channels x "
                         "%d-sample buffers @ %d Hz per GPU (BASELINE configs[2]%s)"
