@@ -236,58 +236,84 @@ inline IirScanConsts make_scan_consts(const BiquadCoeffs& c, int M) {
 // golden's range test on the FLAT index (cuda/bench_conv1d.cu:188-208).  One
 // workgroup = 256 consecutive outputs of one track; taps and the input window
 // are staged in LDS in chunks of kTapChunk taps.
+//
+// The sum is a strictly ordered chain of roundings (that is what makes it
+// bit-identical to the golden), so the only freedom is to keep everything else
+// off that chain: the products, and the LDS reads, which run one group of 16
+// taps ahead of the adds that use them (two register sets; taps are read as
+// broadcasts from LDS rather than through the scalar cache, because LDS returns
+// in order and can be waited for by count).  A kernel lasts as long as its
+// longest chain, so the tiles at the very start of the stream — where the
+// golden SKIPS the taps that reach before sample 0 — run the same pipeline with
+// a select on the chain instead of a branch (START).
 // ---------------------------------------------------------------------------
 constexpr int kTapChunk = 1024;
 constexpr int kConvTile = 256;
+constexpr int kTapGroup = 16;
+
+template <bool START>
+__device__ __forceinline__ float conv1d_tile(const float* __restrict__ in, const float* __restrict__ h, int L,
+                                             long flat0, long total, float* taps, float* win) {
+    const int tid = threadIdx.x;
+    float acc = 0.0f;
+    for (int j0 = 0; j0 < L; j0 += kTapChunk) {
+        const int nj = (L - j0) < kTapChunk ? (L - j0) : kTapChunk;
+        // win[kTapGroup + m] = xflat[wbase + m], m in [0, nj-1+tile); the kTapGroup floats in front
+        // of it and behind the taps are only ever prefetched, never used
+        const long wbase = flat0 - j0 - (nj - 1);
+        for (int m = tid; m < nj; m += kConvTile) taps[m] = h[j0 + m];
+        for (int m = tid; m < nj - 1 + kConvTile; m += kConvTile) {
+            const long g = wbase + m;
+            win[kTapGroup + m] = (g >= 0 && g < total) ? in[g] : 0.0f;   // a ragged last tile overhangs
+        }
+        if (tid < kTapGroup) win[tid] = 0.0f;
+        __syncthreads();
+        const float* w = win + kTapGroup + (nj - 1) + tid;      // w[-jj]: this output's sample at tap jj
+        const int valid = (int)(flat0 + tid - j0 < nj ? flat0 + tid - j0 : nj);   // START: taps 0..valid are in range
+        float xa[kTapGroup], xb[kTapGroup], ha[kTapGroup], hb[kTapGroup];
+        auto fetch = [&](float (&x)[kTapGroup], float (&hh)[kTapGroup], int at) {
+#pragma unroll
+            for (int k = 0; k < kTapGroup; ++k) { x[k] = w[-at - k]; hh[k] = taps[at + k]; }
+        };
+        auto chain = [&](const float (&x)[kTapGroup], const float (&hh)[kTapGroup], int at) {
+#pragma unroll
+            for (int k = 0; k < kTapGroup; ++k) {
+                const float next = __fadd_rn(acc, __fmul_rn(hh[k], x[k]));
+                acc = (!START || at + k <= valid) ? next : acc;     // the golden skips, it does not add zero
+            }
+        };
+        int jj = 0;
+        fetch(xa, ha, 0);
+        for (; jj + 2 * kTapGroup <= nj; jj += 2 * kTapGroup) {
+            fetch(xb, hb, jj + kTapGroup);
+            chain(xa, ha, jj);
+            fetch(xa, ha, jj + 2 * kTapGroup);                  // at the end: the pads
+            chain(xb, hb, jj + kTapGroup);
+        }
+        if (jj + kTapGroup <= nj) { chain(xa, ha, jj); jj += kTapGroup; }
+        for (; jj < nj; ++jj) {
+            const float next = __fadd_rn(acc, __fmul_rn(taps[jj], w[-jj]));
+            acc = (!START || jj <= valid) ? next : acc;
+        }
+        __syncthreads();
+    }
+    return acc;
+}
 
 __global__ __launch_bounds__(kConvTile) void conv1d_direct_kernel(const float* __restrict__ in,
                                                                  float* __restrict__ out,
                                                                  const float* __restrict__ ir,
                                                                  int L, int T, int B) {
-    __shared__ float taps[kTapChunk];
-    __shared__ float win[kTapChunk + kConvTile];
+    __shared__ float taps[kTapChunk + 2 * kTapGroup];
+    __shared__ float win[kTapGroup + kTapChunk + kConvTile];
     const int t = blockIdx.y;
     const int i0 = blockIdx.x * kConvTile;
-    const int tid = threadIdx.x;
     const long flat0 = (long)t * B + i0;           // flat index of this tile's first output
     const long total = (long)T * B;
-    float acc = 0.0f;
-    for (int j0 = 0; j0 < L; j0 += kTapChunk) {
-        const int nj = (L - j0) < kTapChunk ? (L - j0) : kTapChunk;
-        // window element m holds xflat[flat0 - j0 - (nj-1) + m], m in [0, nj-1+tile)
-        const long wbase = flat0 - j0 - (nj - 1);
-        for (int m = tid; m < nj; m += kConvTile) taps[m] = ir[(size_t)t * L + j0 + m];
-        for (int m = tid; m < nj - 1 + kConvTile; m += kConvTile) {
-            long g = wbase + m;
-            win[m] = (g >= 0 && g < total) ? in[g] : 0.0f;
-        }
-        __syncthreads();
-        // output i0+tid at tap j0+jj reads flat index flat0+tid-j0-jj = wbase + (nj-1) + tid - jj
-        const long first_valid = flat0 + tid - j0;   // flat index at jj = 0
-        const int top = nj - 1 + tid;
-        // The sum is a strictly ordered chain of roundings (that is what makes it
-        // bit-identical to the golden), so the only freedom is to keep everything
-        // else off that chain: fetch 8 taps and 8 samples per trip, then add in order.
-        int jj = 0;
-        for (; jj + 8 <= nj; jj += 8) {
-            float h[8], x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { h[k] = taps[jj + k]; x[k] = win[top - jj - k]; }
-            if (first_valid - (jj + 7) >= 0) {       // whole group in range (all but the very start)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc = __fadd_rn(acc, __fmul_rn(h[k], x[k]));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (first_valid - (jj + k) >= 0) acc = __fadd_rn(acc, __fmul_rn(h[k], x[k]));
-            }
-        }
-        for (; jj < nj; ++jj)
-            if (first_valid - jj >= 0)               // golden skips taps that fall before sample 0
-                acc = __fadd_rn(acc, __fmul_rn(taps[jj], win[top - jj]));
-        __syncthreads();
-    }
-    if (i0 + tid < B) out[(size_t)t * B + i0 + tid] = acc;
+    const float* h = ir + (size_t)t * L;
+    const float acc = flat0 >= L - 1 ? conv1d_tile<false>(in, h, L, flat0, total, taps, win)
+                                     : conv1d_tile<true>(in, h, L, flat0, total, taps, win);
+    if (i0 + (int)threadIdx.x < B) out[(size_t)t * B + i0 + threadIdx.x] = acc;
 }
 
 // ---------------------------------------------------------------------------

@@ -15,9 +15,10 @@ CASES = [
     ("Conv1D_accel", dict(n_tracks=1024, ir_length=4096)),
     ("Conv1D_accel", dict(n_tracks=1024, ir_length=4096, conv_mode=gab.CONV_STATELESS)),
     ("Conv1D_accel", dict(n_tracks=128)),
-    ("ModalFilterBank", {}), ("DWG1DNaive", dict(n_tracks=128)), ("DWG1DAccel", dict(n_tracks=128)),
+    ("ModalFilterBank", {}), ("ModalFilterBank", dict(n_tracks=1024, modal_mode=1)), ("DWG1DNaive", dict(n_tracks=128)), ("DWG1DAccel", dict(n_tracks=128)),
     ("DWG1DAccel", dict(n_tracks=1024)),
     ("FDTD3D", dict(n_tracks=128, buffer_size=64)), ("FDTD3D", dict(n_tracks=128, buffer_size=64, fdtd_grid=128)),
+    ("FDTD3D", dict(n_tracks=16, buffer_size=16, fdtd_grid=256)),
     ("RndMemRead", dict(n_tracks=128)), ("RndMemRead", dict(n_tracks=8192)), ("RndMemRead", dict(n_tracks=65536)),
 ]
 only = sys.argv[1:]
