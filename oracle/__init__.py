@@ -15,6 +15,9 @@ _SO = os.path.join(_HERE, "libgab_oracle.so")
 
 
 def build(force=False):
+    override = os.environ.get("GAB_ORACLE_LIB")       # e.g. the sanitizer build (see the Makefile)
+    if override:
+        return os.path.abspath(override)
     src = [os.path.join(_HERE, f) for f in ("gab_oracle.c", "gab_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
@@ -54,8 +57,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        _lib = C.CDLL(build())
         _lib.orc_fnv1a64.restype = C.c_uint64
         _lib.orc_fnv1a64_survey.restype = C.c_uint64
         _lib.orc_rand.restype = C.c_int
