@@ -37,6 +37,22 @@ N_INPUT_BUFFERS = 16            # distinct input buffers cycled through (32 MiB 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def cpu_threads():
+    """Threads for the CPU baseline: GAB_BENCH_CPU_THREADS, else the smallest of the affinity mask,
+    the cgroup CPU quota and 16 (a one-GPU box's CPU share)."""
+    env = os.environ.get("GAB_BENCH_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    n = min(len(os.sched_getaffinity(0)), 16)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def algorithmic_bytes(tracks, bufsize, taps):
     # SURVEY §8d: new input + output + every tap + every history sample the taps reach
     return 4 * tracks * (2 * bufsize + 2 * taps)
@@ -296,25 +312,51 @@ def main():
     # ---- CPU baseline: the oracle, one core, bounded sample (rank 0, N = 1) ------------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         import oracle                     # checker / baseline only — never the product path
-        ir_host = ir_dev.cpu().numpy().ravel()
+        from concurrent.futures import ThreadPoolExecutor
+        ir_host = ir_dev.cpu().numpy().reshape(T, L)
+        xs = [inputs[i].cpu().numpy().reshape(T, B) for i in range(N_INPUT_BUFFERS)]
+        budget = args.cpu_baseline_seconds / 2.0
+
+        # (i) the reference's golden as it runs it: scalar loops, one thread
         hist = np.zeros(T * L, np.float32)
-        x = inputs[0].cpu().numpy().ravel()
         t1 = time.perf_counter()
-        oracle.conv_accel_stream(x, ir_host, hist, L, B, T)
+        oracle.conv_accel_stream(xs[0].ravel(), ir_host.ravel(), hist, L, B, T)
         first = time.perf_counter() - t1
-        n_more = max(1, min(20, int(args.cpu_baseline_seconds / first) - 1))
+        n_one = max(1, min(20, int(budget / first) - 1))
         t1 = time.perf_counter()
-        for i in range(n_more):
-            oracle.conv_accel_stream(inputs[(i + 1) % N_INPUT_BUFFERS].cpu().numpy().ravel(),
-                                     ir_host, hist, L, B, T)
-        dt = time.perf_counter() - t1
+        for i in range(n_one):
+            oracle.conv_accel_stream(xs[(i + 1) % N_INPUT_BUFFERS].ravel(), ir_host.ravel(), hist, L, B, T)
+        dt_one = time.perf_counter() - t1
+
+        # (ii) the same loops with the channels cut over every core this process may use (the
+        # library call releases the interpreter lock; channels are independent)
+        cores = max(1, min(cpu_threads(), T))
+        cuts = [sharding.shard_range(k, cores, T) for k in range(cores)]
+        hists = [np.zeros((hi - lo) * L, np.float32) for lo, hi in cuts]
+        irs = [np.ascontiguousarray(ir_host[lo:hi]).ravel() for lo, hi in cuts]
+        xcut = [[np.ascontiguousarray(x[lo:hi]).ravel() for lo, hi in cuts] for x in xs]
+
+        def one(k, i):
+            lo, hi = cuts[k]
+            oracle.conv_accel_stream(xcut[i % N_INPUT_BUFFERS][k], irs[k], hists[k], L, B, hi - lo)
+
+        with ThreadPoolExecutor(max_workers=cores) as pool:
+            list(pool.map(lambda k: one(k, 0), range(cores)))            # warm
+            n_all = max(2, min(200, int(budget * cores / first * 0.8)))
+            t1 = time.perf_counter()
+            for i in range(n_all):
+                list(pool.map(lambda k, i=i: one(k, i + 1), range(cores)))
+            dt_all = time.perf_counter() - t1
         result["cpu_baseline"] = {
-            "value": n_more / dt,
+            "value": n_all / dt_all,
             "unit": "buffers/s",
-            "cores": 1,
+            "cores": cores,
             "kind": "port",
             "sample": "%d buffers of the full %d-channel x %d-tap workload, direct-form fp32 "
-                      "(oracle/gab_oracle.c orc_conv_accel_stream), %.1f s" % (n_more, T, L, dt),
+                      "(oracle/gab_oracle.c orc_conv_accel_stream), channels cut over %d threads, %.1f s; "
+                      "single thread (as the reference runs its golden): %d buffers in %.1f s"
+                      % (n_all, T, L, cores, dt_all, n_one, dt_one),
+            "single_thread_value": n_one / dt_one,
         }
     elif rank == 0:
         result["cpu_baseline"] = None
