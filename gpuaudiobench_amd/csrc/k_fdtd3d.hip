@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "gab_common.hpp"
@@ -75,6 +76,30 @@ __global__ void fdtd_broadcast_kernel(const float* __restrict__ strip, float* __
     int t = blockIdx.y;
     if (i >= count) return;
     out[(size_t)t * B + first + i] = strip[first + i];
+}
+
+// Track-dependent source / receiver cells (gab_fdtd_set_track_positions): between two samples,
+// ONE workgroup first reads every track's receiver cell for the sample that just closed, then —
+// after a barrier, a receiver may also be somebody's source — adds the next sample of every
+// track into its source cell.  Tracks that share a source cell form a group handled by one
+// thread in track order, so the sum is the oracle's whatever the cells are.
+__global__ __launch_bounds__(256) void fdtd_track_io_kernel(float* __restrict__ p, const float* __restrict__ in,
+                                                            float* __restrict__ out, int T, int B, int extract_sample,
+                                                            int inject_sample, const long long* __restrict__ rcv,
+                                                            int n_groups, const long long* __restrict__ group_cell,
+                                                            const int* __restrict__ group_start,
+                                                            const int* __restrict__ group_tracks) {
+    if (extract_sample >= 0)
+        for (int t = threadIdx.x; t < T; t += blockDim.x)
+            out[(size_t)t * B + extract_sample] = __fmul_rn(p[rcv[t]], 0.1f);      // FDTD3D_OUTPUT_SCALE
+    __syncthreads();
+    if (inject_sample >= 0)
+        for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+            float v = p[group_cell[g]];
+            for (int k = group_start[g]; k < group_start[g + 1]; ++k)
+                v = __fadd_rn(v, __fmul_rn(in[(size_t)group_tracks[k] * B + inject_sample], 0.1f));
+            p[group_cell[g]] = v;
+        }
 }
 
 // One leapfrog step, old fields -> new fields.
@@ -353,6 +378,10 @@ struct gab_fdtd_plan {
     // base pointers (real base minus the slab's offset), so the kernels index with global z.
     int z_begin = 0, z_end = 0;
     gab::Fields cur_real{}, nxt_real{};
+    // track-dependent source / receiver cells (0 tracks: the shared cells of P)
+    int pos_tracks = 0, pos_groups = 0;
+    long long *d_pos_rcv = nullptr, *d_pos_group_cell = nullptr;
+    int *d_pos_group_start = nullptr, *d_pos_group_tracks = nullptr;
     bool use_graphs = true;
     bool lds_tiles = true;    // rows wide enough to fill a 32-lane row of the LDS-halo kernel (GAB_FDTD_LDS=0: off)
     hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
@@ -367,6 +396,16 @@ void free_fields(gab::Fields& f) {
     if (f.vy) (void)hipFree(f.vy);
     if (f.vz) (void)hipFree(f.vz);
     f = gab::Fields{};
+}
+
+void free_track_positions(gab_fdtd_plan* f) {
+    if (f->d_pos_rcv) (void)hipFree(f->d_pos_rcv);
+    if (f->d_pos_group_cell) (void)hipFree(f->d_pos_group_cell);
+    if (f->d_pos_group_start) (void)hipFree(f->d_pos_group_start);
+    if (f->d_pos_group_tracks) (void)hipFree(f->d_pos_group_tracks);
+    f->d_pos_rcv = f->d_pos_group_cell = nullptr;
+    f->d_pos_group_start = f->d_pos_group_tracks = nullptr;
+    f->pos_tracks = f->pos_groups = 0;
 }
 
 void alloc_fields(gab::Fields& f, const gab_fdtd_plan& pl) {
@@ -532,6 +571,7 @@ int gab_fdtd_destroy(gab_fdtd_plan* f) {
     free_fields(f->nxt_real);
     if (f->inj) (void)hipFree(f->inj);
     if (f->strip) (void)hipFree(f->strip);
+    free_track_positions(f);
     delete f;
     return GAB_OK;
 }
@@ -564,7 +604,25 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         const int last = first_sample + n_samples;
 
         // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
+        if (f->pos_tracks && f->pos_tracks != tracks)
+            return gab::bad_arg("gab_fdtd_process: the plan has track positions for a different track count");
         auto enqueue = [&](hipStream_t q, gab::Fields cur, gab::Fields nxt) {
+            if (f->pos_tracks) {
+                auto io = [&](float* p, int extract, int inject) {
+                    gab::fdtd_track_io_kernel<<<1, 256, 0, q>>>(p, d_in, d_out, tracks, bufsize, extract, inject,
+                                                               f->d_pos_rcv, f->pos_groups, f->d_pos_group_cell,
+                                                               f->d_pos_group_start, f->d_pos_group_tracks);
+                };
+                io(cur.p, -1, first_sample);
+                for (int smp = first_sample; smp < last; ++smp) {
+                    for (int step = 0; step < P.steps_per_sample; ++step) {
+                        launch_step(f, q, cur, nxt, nullptr, nullptr);
+                        std::swap(cur, nxt);
+                    }
+                    io(cur.p, smp, smp + 1 < last ? smp + 1 : -1);
+                }
+                return;
+            }
             gab::fdtd_source_sums_kernel<<<(n_samples + 127) / 128, 128, 0, q>>>(d_in, f->inj, tracks, bufsize,
                                                                                first_sample, n_samples);
             // the first sample's source goes straight into the current pressure grid; later
@@ -622,6 +680,55 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             std::swap(f->cur_real, f->nxt_real);
         }
         return gab::launch_status("fdtd kernels");
+    });
+}
+
+int gab_fdtd_set_track_positions(gab_fdtd_plan* f, const int* src_xyz, const int* rcv_xyz, int tracks) {
+    return gab::guarded([&]() -> int {
+        if (!f) return gab::bad_arg("gab_fdtd_set_track_positions: null plan");
+        const gab_fdtd_params& P = f->P;
+        if (f->z_begin != 0 || f->z_end != P.nz)
+            return gab::bad_arg("gab_fdtd_set_track_positions: not available on a z-slab");
+        if (tracks < 0 || (tracks > 0 && (!src_xyz || !rcv_xyz)))
+            return gab::bad_arg("gab_fdtd_set_track_positions: null positions");
+        const size_t sxy = (size_t)P.nx * P.ny;
+        auto cell = [&](const int* q, long long* out) {
+            if (q[0] < 0 || q[0] >= P.nx || q[1] < 0 || q[1] >= P.ny || q[2] < 0 || q[2] >= P.nz) return false;
+            *out = (long long)(q[2] * sxy + (size_t)q[1] * P.nx + q[0]);
+            return true;
+        };
+        std::vector<long long> rcv(tracks), src(tracks);
+        for (int t = 0; t < tracks; ++t)
+            if (!cell(src_xyz + 3 * t, &src[t]) || !cell(rcv_xyz + 3 * t, &rcv[t]))
+                return gab::bad_arg("gab_fdtd_set_track_positions: a position lies outside the grid");
+        GAB_HIP_CHECK(hipDeviceSynchronize());
+        for (auto& c : f->graphs) (void)hipGraphExecDestroy(c.second);     // captured for the old cells
+        f->graphs.clear();
+        free_track_positions(f);
+        if (tracks == 0) return GAB_OK;
+        // tracks that share a source cell, in track order (stable sort by cell)
+        std::vector<int> order(tracks);
+        for (int t = 0; t < tracks; ++t) order[t] = t;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return src[a] < src[b]; });
+        std::vector<long long> gcell;
+        std::vector<int> gstart;
+        for (int k = 0; k < tracks; ++k)
+            if (k == 0 || src[order[k]] != src[order[k - 1]]) {
+                gcell.push_back(src[order[k]]);
+                gstart.push_back(k);
+            }
+        gstart.push_back(tracks);
+        auto upload = [](auto** d, const auto& h) {
+            GAB_HIP_CHECK(hipMalloc(d, h.size() * sizeof(h[0])));
+            GAB_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(h[0]), hipMemcpyHostToDevice));
+        };
+        upload(&f->d_pos_rcv, rcv);
+        upload(&f->d_pos_group_cell, gcell);
+        upload(&f->d_pos_group_start, gstart);
+        upload(&f->d_pos_group_tracks, order);
+        f->pos_tracks = tracks;
+        f->pos_groups = (int)gcell.size();
+        return GAB_OK;
     });
 }
 

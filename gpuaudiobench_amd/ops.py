@@ -225,6 +225,21 @@ class FdtdPlan:
                                    n_samples, _stream()))
         return out
 
+    def set_track_positions(self, src_xyz, rcv_xyz):
+        """Per-track source and receiver cells: two (tracks, 3) integer arrays of (x, y, z);
+        pass None, None to return to the shared cells of the params."""
+        import numpy as np
+        if src_xyz is None:
+            check(lib.gab_fdtd_set_track_positions(self._h, None, None, 0))
+            return
+        src = np.ascontiguousarray(src_xyz, np.int32)
+        rcv = np.ascontiguousarray(rcv_xyz, np.int32)
+        if src.ndim != 2 or src.shape[1] != 3 or rcv.shape != src.shape:
+            raise ValueError("positions must be two (tracks, 3) arrays")
+        ip = C.POINTER(C.c_int)
+        check(lib.gab_fdtd_set_track_positions(self._h, src.ctypes.data_as(ip), rcv.ctypes.data_as(ip),
+                                               src.shape[0]))
+
     def pressure(self):
         """A copy of the pressure grid as a torch tensor (nz, ny, nx)."""
         P = self.params

@@ -198,6 +198,13 @@ int gab_fdtd_reset(gab_fdtd_plan* plan, gab_stream_t stream);     /* zero grids 
 int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
                      int tracks, int bufsize, int first_sample, int n_samples,
                      gab_stream_t stream);
+/* Track-dependent source and receiver cells — announced and never done by the Metal port
+ * ("can be made track-dependent later", kernels_fdtd3d.metal:184,217).  src_xyz / rcv_xyz: HOST
+ * arrays, tracks x (x, y, z).  From then on gab_fdtd_process (with that many tracks) adds
+ * 0.1*in[t,s] into track t's source cell — tracks in order, so a cell shared by several tracks
+ * receives their samples in track order — and writes out[t,s] = 0.1*p[receiver cell of t].
+ * tracks = 0 returns to the shared cells of the params.                                          */
+int gab_fdtd_set_track_positions(gab_fdtd_plan* plan, const int* src_xyz, const int* rcv_xyz, int tracks);
 /* ---- z-slab domain decomposition (Metal comments kernels_fdtd3d.metal:184,217) ----
  * A plan that owns planes [z_begin, z_end) of the global grid, with one ghost pressure plane below
  * and above and one ghost vz face plane above.  One leapfrog step needs, from the slab below, its

@@ -306,6 +306,18 @@ def fdtd(P, grids, x, out, tracks, bufsize, first_sample, n_samples, fused=True)
     return out
 
 
+def fdtd_tracks(P, grids, x, out, tracks, bufsize, first_sample, n_samples, src_xyz, rcv_xyz, fused=True):
+    """Track-dependent source / receiver cells (tracks x 3 int32 each, (x, y, z))."""
+    p, vx, vy, vz = grids
+    src = np.ascontiguousarray(src_xyz, np.int32)
+    rcv = np.ascontiguousarray(rcv_xyz, np.int32)
+    assert src.shape == (tracks, 3) and rcv.shape == (tracks, 3)
+    lib().orc_fdtd_tracks(C.byref(P), _p(p), _p(vx), _p(vy), _p(vz), _p(_f32(x)), _p(out),
+                          C.c_int(tracks), C.c_int(bufsize), C.c_int(first_sample),
+                          C.c_int(n_samples), C.c_int(1 if fused else 0), _p(src), _p(rcv))
+    return out
+
+
 # ---- rndmem ------------------------------------------------------------------
 RNDMEM_POOL_ELEMS = 512 * 1024 * 1024 // 4
 

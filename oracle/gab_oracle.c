@@ -501,80 +501,99 @@ void orc_fdtd_placeholder(const float* in, float* out, int tracks, int bufsize) 
  * runFDTD3DTimeStep (:384-438).  The atomicAdd injection is fixed to "sum the
  * tracks in order, add the sum once".  `fused` selects the single-rounding a-=c*d nvcc emits for the
  * kernels (-fmad=true); fused==0 is the two-rounding host form.             */
-void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
-              float* vz, const float* in, float* out, int tracks, int bufsize,
-              int first_sample, int n_samples, int fused) {
+static void fdtd_step(const orc_fdtd_params* P, float* p, float* vx, float* vy, float* vz, int fused) {
     const int nx = P->nx, ny = P->ny, nz = P->nz;
     const size_t sxy = (size_t)nx * ny;
     const float c1 = P->dt_over_rho_dx, c2 = P->rho_c2_dt_over_dx;
     const float damp = 1.0f - P->absorption;
-    const size_t src = (size_t)P->src_z * sxy + (size_t)P->src_y * nx + P->src_x;
-    const size_t rcv = (size_t)P->rcv_z * sxy + (size_t)P->rcv_y * nx + P->rcv_x;
+    /* velocity (interior faces) */
+    for (int z = 0; z < nz; ++z)
+        for (int y = 0; y < ny; ++y) {
+            const float* pr = p + z * sxy + (size_t)y * nx;
+            float* vr = vx + ((size_t)z * ny + y) * (nx + 1);
+            for (int x = 1; x < nx; ++x) {
+                float d = pr[x] - pr[x - 1];
+                vr[x] = fused ? fmaf(-c1, d, vr[x]) : vr[x] - c1 * d;
+            }
+        }
+    for (int z = 0; z < nz; ++z)
+        for (int y = 1; y < ny; ++y) {
+            const float* pr = p + z * sxy + (size_t)y * nx;
+            float* vr = vy + ((size_t)z * (ny + 1) + y) * nx;
+            for (int x = 0; x < nx; ++x) {
+                float d = pr[x] - pr[x - nx];
+                vr[x] = fused ? fmaf(-c1, d, vr[x]) : vr[x] - c1 * d;
+            }
+        }
+    for (int z = 1; z < nz; ++z)
+        for (int y = 0; y < ny; ++y) {
+            const float* pr = p + z * sxy + (size_t)y * nx;
+            float* vr = vz + z * sxy + (size_t)y * nx;
+            for (int x = 0; x < nx; ++x) {
+                float d = pr[x] - pr[x - (long)sxy];
+                vr[x] = fused ? fmaf(-c1, d, vr[x]) : vr[x] - c1 * d;
+            }
+        }
+
+    /* pressure */
+    for (int z = 0; z < nz; ++z)
+        for (int y = 0; y < ny; ++y) {
+            float* pr = p + z * sxy + (size_t)y * nx;
+            const int edge_zy = (z == 0 || z == nz - 1 || y == 0 || y == ny - 1);
+            if (edge_zy) {
+                for (int x = 0; x < nx; ++x) pr[x] *= damp;
+                continue;
+            }
+            const float* ax = vx + ((size_t)z * ny + y) * (nx + 1);
+            const float* ay = vy + ((size_t)z * (ny + 1) + y) * nx;
+            const float* az = vz + z * sxy + (size_t)y * nx;
+            pr[0] *= damp;
+            for (int x = 1; x < nx - 1; ++x) {
+                float div = (ax[x + 1] - ax[x]) + (ay[x + nx] - ay[x]) +
+                            (az[x + sxy] - az[x]);
+                pr[x] = fused ? fmaf(-c2, div, pr[x]) : pr[x] - c2 * div;
+            }
+            pr[nx - 1] *= damp;
+        }
+}
+
+void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
+              float* vz, const float* in, float* out, int tracks, int bufsize,
+              int first_sample, int n_samples, int fused) {
+    const size_t sxy = (size_t)P->nx * P->ny;
+    const size_t src = (size_t)P->src_z * sxy + (size_t)P->src_y * P->nx + P->src_x;
+    const size_t rcv = (size_t)P->rcv_z * sxy + (size_t)P->rcv_y * P->nx + P->rcv_x;
 
     for (int s = first_sample; s < first_sample + n_samples; ++s) {
-        for (int step = 0; step < P->steps_per_sample; ++step) {
-            if (step == 0) {
-                /* the reference's atomicAdd order is unspecified; fixed here as: scaled
-                 * samples summed in track order, the sum added to the cell once */
-                float acc = 0.0f;
-                for (int t = 0; t < tracks; ++t) acc += in[(size_t)t * bufsize + s] * 0.1f;
-                p[src] += acc;
-            }
+        /* the reference's atomicAdd order is unspecified; fixed here as: scaled
+         * samples summed in track order, the sum added to the cell once */
+        float acc = 0.0f;
+        for (int t = 0; t < tracks; ++t) acc += in[(size_t)t * bufsize + s] * 0.1f;
+        p[src] += acc;
+        for (int step = 0; step < P->steps_per_sample; ++step) fdtd_step(P, p, vx, vy, vz, fused);
+        float o = p[rcv] * 0.1f;
+        for (int t = 0; t < tracks; ++t) out[(size_t)t * bufsize + s] = o;
+    }
+}
 
-            /* velocity (interior faces) */
-            for (int z = 0; z < nz; ++z)
-                for (int y = 0; y < ny; ++y) {
-                    const float* pr = p + z * sxy + (size_t)y * nx;
-                    float* vr = vx + ((size_t)z * ny + y) * (nx + 1);
-                    for (int x = 1; x < nx; ++x) {
-                        float d = pr[x] - pr[x - 1];
-                        vr[x] = fused ? fmaf(-c1, d, vr[x]) : vr[x] - c1 * d;
-                    }
-                }
-            for (int z = 0; z < nz; ++z)
-                for (int y = 1; y < ny; ++y) {
-                    const float* pr = p + z * sxy + (size_t)y * nx;
-                    float* vr = vy + ((size_t)z * (ny + 1) + y) * nx;
-                    for (int x = 0; x < nx; ++x) {
-                        float d = pr[x] - pr[x - nx];
-                        vr[x] = fused ? fmaf(-c1, d, vr[x]) : vr[x] - c1 * d;
-                    }
-                }
-            for (int z = 1; z < nz; ++z)
-                for (int y = 0; y < ny; ++y) {
-                    const float* pr = p + z * sxy + (size_t)y * nx;
-                    float* vr = vz + z * sxy + (size_t)y * nx;
-                    for (int x = 0; x < nx; ++x) {
-                        float d = pr[x] - pr[x - (long)sxy];
-                        vr[x] = fused ? fmaf(-c1, d, vr[x]) : vr[x] - c1 * d;
-                    }
-                }
-
-            /* pressure */
-            for (int z = 0; z < nz; ++z)
-                for (int y = 0; y < ny; ++y) {
-                    float* pr = p + z * sxy + (size_t)y * nx;
-                    const int edge_zy = (z == 0 || z == nz - 1 || y == 0 || y == ny - 1);
-                    if (edge_zy) {
-                        for (int x = 0; x < nx; ++x) pr[x] *= damp;
-                        continue;
-                    }
-                    const float* ax = vx + ((size_t)z * ny + y) * (nx + 1);
-                    const float* ay = vy + ((size_t)z * (ny + 1) + y) * nx;
-                    const float* az = vz + z * sxy + (size_t)y * nx;
-                    pr[0] *= damp;
-                    for (int x = 1; x < nx - 1; ++x) {
-                        float div = (ax[x + 1] - ax[x]) + (ay[x + nx] - ay[x]) +
-                                    (az[x + sxy] - az[x]);
-                        pr[x] = fused ? fmaf(-c2, div, pr[x]) : pr[x] - c2 * div;
-                    }
-                    pr[nx - 1] *= damp;
-                }
-
-            if (step == P->steps_per_sample - 1) {
-                float o = p[rcv] * 0.1f;
-                for (int t = 0; t < tracks; ++t) out[(size_t)t * bufsize + s] = o;
-            }
+/* Track-dependent source and receiver cells — what the Metal port's inject/extract kernels
+ * announce ("can be made track-dependent later", kernels_fdtd3d.metal:184,217) and never do:
+ * track t adds 0.1f*in[t,s] into ITS source cell (tracks in order, so cells shared by several
+ * tracks receive their samples in track order) and reads 0.1f*p at ITS receiver cell.
+ * src_xyz / rcv_xyz: tracks x (x, y, z).                                                      */
+void orc_fdtd_tracks(const orc_fdtd_params* P, float* p, float* vx, float* vy, float* vz,
+                     const float* in, float* out, int tracks, int bufsize, int first_sample,
+                     int n_samples, int fused, const int* src_xyz, const int* rcv_xyz) {
+    const size_t sxy = (size_t)P->nx * P->ny;
+    for (int s = first_sample; s < first_sample + n_samples; ++s) {
+        for (int t = 0; t < tracks; ++t) {
+            const size_t c = (size_t)src_xyz[3 * t + 2] * sxy + (size_t)src_xyz[3 * t + 1] * P->nx + src_xyz[3 * t];
+            p[c] += in[(size_t)t * bufsize + s] * 0.1f;
+        }
+        for (int step = 0; step < P->steps_per_sample; ++step) fdtd_step(P, p, vx, vy, vz, fused);
+        for (int t = 0; t < tracks; ++t) {
+            const size_t c = (size_t)rcv_xyz[3 * t + 2] * sxy + (size_t)rcv_xyz[3 * t + 1] * P->nx + rcv_xyz[3 * t];
+            out[(size_t)t * bufsize + s] = p[c] * 0.1f;
         }
     }
 }

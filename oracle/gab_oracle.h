@@ -146,6 +146,9 @@ void orc_fdtd_placeholder(const float* in, float* out, int tracks, int bufsize);
 void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
               float* vz, const float* in, float* out, int tracks, int bufsize,
               int first_sample, int n_samples, int fused);
+void orc_fdtd_tracks(const orc_fdtd_params* P, float* p, float* vx, float* vy, float* vz,
+                     const float* in, float* out, int tracks, int bufsize, int first_sample,
+                     int n_samples, int fused, const int* src_xyz, const int* rcv_xyz);
 
 /* ---- rndmem -------------------------------------------------------------- */
 void orc_rndmem_pool(float* pool, size_t n);                  /* srand(42) */

@@ -583,6 +583,53 @@ def test_fdtd_z_slabs_reproduce_the_single_grid(gab, orc, n, cuts, T, B):
         s.close()
 
 
+@pytest.mark.parametrize("n,T,B", [(20, 5, 10), (52, 12, 24), (128, 6, 4)])
+def test_fdtd_track_dependent_positions(gab, orc, n, T, B):
+    """SURVEY 8f-4, second half: every track with its own source and receiver cell (the Metal
+    port's 'can be made track-dependent later'), bit-exact against the oracle — including
+    tracks that share a source cell (summed in track order), a receiver that is also a source,
+    and cells on the damped boundary shell."""
+    import torch
+    G = gab.fdtd_default_params(n)
+    rng = np.random.RandomState(n)
+    src = rng.randint(1, n - 1, size=(T, 3)).astype(np.int32)
+    rcv = rng.randint(1, n - 1, size=(T, 3)).astype(np.int32)
+    src[1] = src[0]                                   # two tracks, one source cell
+    src[T - 1] = src[0]                               # ... and a third, not adjacent in track order
+    rcv[2] = src[3]                                   # a receiver on another track's source
+    rcv[0] = src[0] + np.array([1, 0, 0], np.int32)   # right next to a source: heard within a step
+    src[4] = (0, n // 2, n // 2)                      # on the boundary shell
+    x = orc.Rand(9).bipolar(T * B)
+    P = orc.fdtd_params(n)
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    plan = gab.FdtdPlan(G)
+    plan.set_track_positions(src, rcv)
+    out = torch.zeros(T * B, device="cuda")
+    half = B // 2
+    for first, cnt in ((0, half), (half, B - half)):
+        orc.fdtd_tracks(P, grids, x, ref, T, B, first, cnt, src, rcv, fused=True)
+        plan.process(dev(x), out, T, B, first, cnt)
+    assert np.array_equal(bits(host(out)), bits(ref))
+    assert np.array_equal(bits(host(plan.pressure()).ravel()), bits(grids[0]))
+    got = host(out).reshape(T, B)
+    assert np.abs(got[0]).max() > 0 and not np.array_equal(got[0], got[1])     # tracks hear different things
+    with pytest.raises(gab.GabError):
+        plan.process(dev(x), out, T + 1, B, 0, 1)     # positions were given for T tracks
+    with pytest.raises(gab.GabError):
+        bad = src.copy()
+        bad[0, 0] = n
+        plan.set_track_positions(bad, rcv)
+    # back to the shared cells: the plan behaves like a fresh one
+    plan.set_track_positions(None, None)
+    plan.reset()
+    grids = orc.fdtd_grids(P)
+    orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+    plan.process(dev(x), out, T, B, 0, B)
+    assert np.array_equal(bits(host(out)), bits(ref))
+    plan.close()
+
+
 def test_fdtd_slab_argument_errors(gab):
     import ctypes as C
     import torch

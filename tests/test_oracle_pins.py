@@ -188,6 +188,33 @@ def test_modal_bank_golden_restatement(orc):
     assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
 
 
+def test_fdtd_track_positions_restatement(orc):
+    """orc_fdtd_tracks: with one track at the shared cells it IS orc_fdtd; a track's output depends
+    only on what reaches its own receiver; tracks sharing a source cell add up in track order."""
+    n, B = 20, 12
+    P = orc.fdtd_params(n)
+    shared_src = np.array([[P.src_x, P.src_y, P.src_z]], np.int32)
+    shared_rcv = np.array([[P.rcv_x, P.rcv_y, P.rcv_z]], np.int32)
+    x = orc.Rand(1).bipolar(B)
+    g1, g2 = orc.fdtd_grids(P), orc.fdtd_grids(P)
+    o1, o2 = np.zeros(B, np.float32), np.zeros(B, np.float32)
+    orc.fdtd(P, g1, x, o1, 1, B, 0, B)
+    orc.fdtd_tracks(P, g2, x, o2, 1, B, 0, B, shared_src, shared_rcv)
+    assert np.array_equal(o1, o2) and np.array_equal(g1[0], g2[0]) and np.abs(g1[0]).max() > 0
+    # two tracks on one source cell: the field is that of their sample-wise sum (track order)
+    x2 = orc.Rand(2).bipolar(2 * B)
+    src = np.repeat(shared_src, 2, axis=0)
+    rcv = np.array([[P.src_x + 1, P.src_y, P.src_z], [P.src_x, P.src_y + 2, P.src_z]], np.int32)
+    g3 = orc.fdtd_grids(P)
+    o3 = np.zeros(2 * B, np.float32)
+    orc.fdtd_tracks(P, g3, x2, o3, 2, B, 0, B, src, rcv)
+    o3 = o3.reshape(2, B)
+    assert np.abs(o3[0]).max() > 0 and np.abs(o3[1]).max() > 0 and not np.array_equal(o3[0], o3[1])
+    # the nearer receiver hears the source first
+    first = lambda v: int(np.flatnonzero(v)[0])
+    assert first(o3[0]) <= first(o3[1])
+
+
 def test_statistics(orc):
     lat = np.array([1.0, 2.0, 3.0, 4.0, 10.0], np.float32)
     s = orc.statistics(lat)
