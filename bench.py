@@ -65,9 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--roundtrip-iters", type=int, default=300)
     ap.add_argument("--paced-iters", type=int, default=150)
-    # off by default: these launches run at PCIe speed under the same kernel name and would skew a
-    # rocprofv3 --stats average of the timed kernel (tools/roundtrip_conv.py measures them too)
-    ap.add_argument("--zero-copy-iters", type=int, default=0)
+    # these launches run at PCIe speed; they use the kernel's host-io name, so a rocprofv3 --stats
+    # average of the timed kernel is not skewed by them
+    ap.add_argument("--zero-copy-iters", type=int, default=300)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

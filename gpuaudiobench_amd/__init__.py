@@ -7,7 +7,7 @@ CUDA(=HIP) tensors for device memory and streams.  Nothing here computes on the
 CPU; if the shared object is missing the import fails.
 """
 from . import _capi
-from ._capi import GabError, lib, check, CONV_STATELESS, CONV_STREAMING, DWG_NAIVE, DWG_ACCEL
+from ._capi import GabError, lib, check, CONV_STATELESS, CONV_STREAMING, CONV_STREAMING_HOST_IO, DWG_NAIVE, DWG_ACCEL
 from .ops import (noop, gain, gainstats, datatransfer, iir, conv1d, rndmem, modal, modal_bank, dwg,
                   fft_r2c_1024, ConvPlan, FdtdPlan, fdtd_default_params, device_count)
 
@@ -16,7 +16,7 @@ from .harness import Benchmark, benchmark_names
 
 __all__ = [
     "harness", "Benchmark", "benchmark_names",
-    "GabError", "lib", "check", "CONV_STATELESS", "CONV_STREAMING", "DWG_NAIVE", "DWG_ACCEL",
+    "GabError", "lib", "check", "CONV_STATELESS", "CONV_STREAMING", "CONV_STREAMING_HOST_IO", "DWG_NAIVE", "DWG_ACCEL",
     "noop", "gain", "gainstats", "datatransfer", "iir", "conv1d", "rndmem", "modal", "modal_bank", "dwg",
     "fft_r2c_1024", "ConvPlan", "FdtdPlan", "fdtd_default_params", "device_count",
 ]

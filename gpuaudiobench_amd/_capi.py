@@ -16,6 +16,7 @@ GAB_ERR_UNSUPPORTED = -3
 
 CONV_STATELESS = 0
 CONV_STREAMING = 1
+CONV_STREAMING_HOST_IO = 2
 DWG_NAIVE = 0
 DWG_ACCEL = 1
 

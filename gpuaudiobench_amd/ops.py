@@ -9,6 +9,7 @@ import ctypes as C
 import torch
 
 from ._capi import (lib, check, WaveguideState, FdtdParams, CONV_STATELESS, CONV_STREAMING,
+                    CONV_STREAMING_HOST_IO,
                     DWG_NAIVE, DWG_ACCEL)
 
 
@@ -153,7 +154,9 @@ class ConvPlan:
             out = torch.empty(self.tracks * self.bufsize, dtype=torch.float32,
                               device=x.device if x.is_cuda else "cuda")
         # x / out may also be pinned host tensors: the kernel then streams the buffer over PCIe
-        # itself (zero-copy), without separate copy commands
+        # itself (zero-copy), without separate copy commands — under its own kernel name
+        if mode == CONV_STREAMING and not x.is_cuda and not out.is_cuda:
+            mode = CONV_STREAMING_HOST_IO
         check(lib.gab_conv_process(self._h, _acc(x), _acc(out), mode, _stream()))
         return out
 

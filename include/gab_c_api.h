@@ -138,6 +138,9 @@ typedef struct gab_conv_plan gab_conv_plan;
 
 #define GAB_CONV_STATELESS 0  /* reference semantics: zero history each call  */
 #define GAB_CONV_STREAMING 1  /* overlap-save with carried history            */
+#define GAB_CONV_STREAMING_HOST_IO 2  /* the same, d_in / d_out in pinned host memory: identical kernel
+                                       * under its own name, so that link-speed launches do not
+                                       * mix into per-kernel profiles of the HBM-resident ones    */
 
 /* allocateAccelBuffers + setupFFTPlans (:88-150).  Allocates the spectra bank
  * and the history ring on the current device.                                */
