@@ -12,7 +12,7 @@ namespace gab {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 2048;     // 256 CUs x 8 blocks: grid-stride beyond that
+constexpr int kMaxGrid = 8192;     // 256 CUs x 32 blocks: grid-stride beyond that
 
 inline int grid_for(size_t work_items) {
     size_t g = (work_items + kBlock - 1) / kBlock;
@@ -30,12 +30,20 @@ __global__ __launch_bounds__(kBlock) void scale_vec4_kernel(const float4* __rest
                                                            const float* __restrict__ in_tail,
                                                            float* __restrict__ out_tail, int tail,
                                                            float gain) {
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (; i < n4; i += stride) {
-        float4 v = in[i];
-        if (SCALE) { v.x = gain * v.x; v.y = gain * v.y; v.z = gain * v.z; v.w = gain * v.w; }
-        out[i] = v;
+    // a workgroup takes kUnroll consecutive 4 KiB rows; every lane has kUnroll 16-byte loads in
+    // flight before its first store
+    constexpr int kUnroll = 4;
+    const size_t stride = (size_t)gridDim.x * kBlock * kUnroll;
+    for (size_t base = (size_t)blockIdx.x * kBlock * kUnroll + threadIdx.x; base < n4; base += stride) {
+        float4 v[kUnroll];
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+            if (base + (size_t)k * kBlock < n4) v[k] = in[base + (size_t)k * kBlock];
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k) {
+            if (SCALE) { v[k].x = gain * v[k].x; v[k].y = gain * v[k].y; v[k].z = gain * v[k].z; v[k].w = gain * v[k].w; }
+            if (base + (size_t)k * kBlock < n4) out[base + (size_t)k * kBlock] = v[k];
+        }
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < tail)
         out_tail[threadIdx.x] = SCALE ? gain * in_tail[threadIdx.x] : in_tail[threadIdx.x];
@@ -56,7 +64,7 @@ int launch_scale(const float* d_in, float* d_out, size_t n, float gain, hipStrea
     if (aligned16(d_in) && aligned16(d_out)) {
         size_t n4 = n / 4;
         int tail = (int)(n - 4 * n4);
-        scale_vec4_kernel<SCALE><<<grid_for(n4), kBlock, 0, s>>>(
+        scale_vec4_kernel<SCALE><<<grid_for((n4 + 3) / 4), kBlock, 0, s>>>(
             reinterpret_cast<const float4*>(d_in), reinterpret_cast<float4*>(d_out), n4,
             d_in + 4 * n4, d_out + 4 * n4, tail, gain);
     } else {
