@@ -735,3 +735,38 @@ def test_random_shapes_rndmem_and_modal_bank(gab, orc, T, B):
 def torch_i32(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a, np.int32)).cuda()
+
+
+def test_plans_release_their_device_memory(gab):
+    """Every plan frees what it allocated (spectra, history ring, FDTD fields, cached graphs):
+    free device memory is back where it started after many create / use / close cycles."""
+    import torch
+    T, B, L = 256, 512, 4096
+    ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
+    x = torch.from_numpy(gab.harness.noise(T * B)).cuda()
+    xf = torch.from_numpy(gab.harness.noise(4 * 16)).cuda()
+    out = torch.empty(T * B, device="cuda")
+    outf = torch.empty(4 * 16, device="cuda")
+
+    def cycle():
+        plan = gab.ConvPlan(T, B, L)
+        plan.set_ir(ir)
+        plan.process(x, out=out)
+        plan.close()
+        f = gab.FdtdPlan(gab.fdtd_default_params(64))
+        f.process(xf, outf, 4, 16, 0, 16)                 # 51 launches: goes through a captured graph
+        f.close()
+        from gpuaudiobench_amd import fdtd_slabs as fs
+        slabs = [fs.FdtdSlab(gab.fdtd_default_params(32), a, b) for a, b in fs.slab_ranges(32, 2)]
+        fs.process_local(slabs, xf, outf, 4, 16)
+        for s in slabs:
+            s.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)      # one cycle allocates > 60 MiB
