@@ -19,7 +19,8 @@
  * reference's own golden functions) — see tests/test_oracle_pins.py.
  * Not pinned by any reference output ("parity unpinned" there): the real
  * FDTD3D field evolution (the reference golden is a placeholder), streaming
- * conv1d_accel beyond the first buffer, the real modal bank.
+ * conv1d_accel beyond the first buffer, the real modal bank, FDTD3D with
+ * track-dependent source / receiver cells (orc_fdtd_tracks).
  *
  * Build: gcc -O2 -ffp-contract=off (see oracle/Makefile).  Contraction is off
  * so a*b+c is two roundings, as in the reference's host build; where the
