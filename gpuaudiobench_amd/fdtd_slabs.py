@@ -121,19 +121,27 @@ def exchange_local(slabs):
 
 def exchange_ranks(slab, rank, world, dist):
     """One slab per rank, rank k below rank k+1: one batch of point-to-point sends and
-    receives with the two neighbours."""
-    ops = []
+    receives with the two neighbours.  Device planes go as they are over RCCL; a backend that
+    only moves host memory (gloo, used to rehearse the multi-rank path on one device) gets them
+    staged through host copies."""
+    plan = []                                              # (is_send, plane, peer)
     if rank + 1 < world:
-        ops += [dist.P2POp(dist.isend, slab.halo(SEND_UP_P), rank + 1),
-                dist.P2POp(dist.irecv, slab.halo(RECV_UP_P), rank + 1),
-                dist.P2POp(dist.irecv, slab.halo(RECV_UP_VZ), rank + 1)]
+        plan += [(True, slab.halo(SEND_UP_P), rank + 1), (False, slab.halo(RECV_UP_P), rank + 1),
+                 (False, slab.halo(RECV_UP_VZ), rank + 1)]
     if rank > 0:
-        ops += [dist.P2POp(dist.irecv, slab.halo(RECV_DOWN_P), rank - 1),
-                dist.P2POp(dist.isend, slab.halo(SEND_DOWN_P), rank - 1),
-                dist.P2POp(dist.isend, slab.halo(SEND_DOWN_VZ), rank - 1)]
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        plan += [(False, slab.halo(RECV_DOWN_P), rank - 1), (True, slab.halo(SEND_DOWN_P), rank - 1),
+                 (True, slab.halo(SEND_DOWN_VZ), rank - 1)]
+    if not plan:
+        return
+    staged = plan[0][1].is_cuda and dist.get_backend() != "nccl"
+    bufs = [(t.cpu() if snd else torch.empty(t.shape, dtype=t.dtype)) if staged else t for snd, t, _ in plan]
+    ops = [dist.P2POp(dist.isend if snd else dist.irecv, b, peer) for (snd, _, peer), b in zip(plan, bufs)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if staged:
+        for (snd, t, _), b in zip(plan, bufs):
+            if not snd:
+                t.copy_(b)
 
 
 def run_buffer(slabs, bufsize, steps_per_sample, exchange):
@@ -165,6 +173,11 @@ def process_ranks(slab, x, out, tracks, bufsize, rank, world, dist):
     owner = next(r for r, (a, b) in enumerate(ranges) if a <= slab.params.receiver_z < b)
     strip = slab.strip()[:bufsize]
     if world > 1:
-        dist.broadcast(strip, src=owner)
+        if strip.is_cuda and dist.get_backend() != "nccl":
+            host = strip.cpu()
+            dist.broadcast(host, src=owner)
+            strip.copy_(host)
+        else:
+            dist.broadcast(strip, src=owner)
     out.view(tracks, bufsize)[:] = strip
     return out

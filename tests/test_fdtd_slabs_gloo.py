@@ -167,3 +167,63 @@ def test_rank_exchange_matches_the_uncut_grid(orc, world):
             assert np.array_equal(gathered[r][2][k].view(np.uint32), want[k].numpy().view(np.uint32))
     assert np.array_equal(np.concatenate([g[3] for g in gathered]), field.numpy())
     assert np.abs(want[-1].numpy()).max() > 0
+
+
+def _gpu_worker(rank, world, port, n, T, B, buffers, seed, q):
+    import oracle
+    import gpuaudiobench_amd as gab
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)                                 # every rank on the one device
+        P = gab.fdtd_default_params(n)
+        a, b = fs.slab_ranges(P.nz, world)[rank]
+        slab = fs.FdtdSlab(P, a, b)
+        x = torch.from_numpy(oracle.Rand(seed).bipolar(T * B)).cuda()
+        outs = []
+        for _ in range(buffers):
+            out = torch.zeros(T * B, device="cuda")
+            fs.process_ranks(slab, x, out, T, B, rank, world, dist)
+            outs.append(out.cpu().numpy())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (a, b, outs, slab.pressure().cpu().numpy()))
+        if rank == 0:
+            q.put(gathered)
+        slab.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_slabs_on_two_ranks_match_the_single_grid(orc):
+    """The multi-rank path with the real kernels: two processes, one device slab each (both on
+    this box's one GPU, planes staged through the host because gloo moves host memory), against
+    the single-grid plan and the oracle, bit for bit."""
+    import gpuaudiobench_amd as gab
+    n, T, B, buffers, seed, world = 52, 4, 16, 2, 11, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n, T, B, buffers, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    x = orc.Rand(seed).bipolar(T * B)
+    P = orc.fdtd_params(n)
+    grids = orc.fdtd_grids(P)
+    plan = gab.FdtdPlan(gab.fdtd_default_params(n))
+    for k in range(buffers):
+        ref = np.zeros(T * B, np.float32)
+        orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+        out = torch.zeros(T * B, device="cuda")
+        plan.process(torch.from_numpy(x).cuda(), out, T, B, 0, B)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        for r in range(world):
+            assert np.array_equal(gathered[r][2][k].view(np.uint32), ref.view(np.uint32))
+    field = np.concatenate([g[3] for g in gathered]).ravel()
+    assert np.array_equal(field.view(np.uint32), grids[0].view(np.uint32))
+    plan.close()
