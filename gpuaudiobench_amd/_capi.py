@@ -17,6 +17,8 @@ GAB_ERR_UNSUPPORTED = -3
 CONV_STATELESS = 0
 CONV_STREAMING = 1
 CONV_STREAMING_HOST_IO = 2
+CONV_SCHEME_CLASSIC = 0
+CONV_SCHEME_SPLIT = 1
 DWG_NAIVE = 0
 DWG_ACCEL = 1
 
@@ -91,6 +93,8 @@ PROTOTYPES = {
     "gab_conv_set_ir": (_I, [_P, _P, _P]),
     "gab_conv_reset": (_I, [_P, _P]),
     "gab_conv_process": (_I, [_P, _P, _P, _I, _P]),
+    "gab_conv_set_scheme": (_I, [_P, _I]),
+    "gab_conv_get_scheme": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_process_batch": (_I, [_P, _P, _P, _I, _P]),
     "gab_conv_process_windowed": (_I, [_P, _P, C.POINTER(C.c_void_p), _P, _P]),
     "gab_conv_state_bytes": (_I, [_P, C.POINTER(_Z), C.POINTER(_Z)]),

@@ -238,6 +238,28 @@ struct Butterfly<16, INV> {
         x14 = sub_rot<INV>(sub_rot<INV>(y2[0], y2[2]), sub_rot<INV>(y2[1], y2[3]));
         x15 = sub_rot<INV>(sub_rot<INV>(y3[0], y3[2]), csub(y3[1], y3[3]));
     }
+
+    // Outputs 12..15 (every k1 with k2 = 3): the last QUARTER of the transform's output, for a
+    // partition that keeps 1024 samples of a 4096-point inverse.  ~70 instructions.
+    __device__ static __forceinline__ void run_last4(const cf (&v)[16], cf& x12, cf& x13, cf& x14, cf& x15) {
+        cf y0[4], y1[4], y2[4], y3[4];
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+            cf t0 = cadd(v[n2], v[8 + n2]), t1 = csub(v[n2], v[8 + n2]);
+            cf t2 = cadd(v[4 + n2], v[12 + n2]), d = csub(v[4 + n2], v[12 + n2]);
+            y0[n2] = cadd(t0, t2);
+            y1[n2] = add_rot<INV>(t1, d);
+            y2[n2] = csub(t0, t2);
+            y3[n2] = sub_rot<INV>(t1, d);
+        }
+        y1[1] = tw16<INV, 1>(y1[1]); y1[2] = tw16<INV, 2>(y1[2]); y1[3] = tw16<INV, 3>(y1[3]);
+        y2[1] = tw16<INV, 2>(y2[1]); y2[3] = tw16<INV, 2>(y2[3]);            // y2[2], y2[3] owe a rot90
+        y3[1] = tw16<INV, 3>(y3[1]); y3[2] = tw16<INV, 2>(y3[2]); y3[3] = tw16<INV, 9>(y3[3]);   // y3[2] owes one
+        x12 = sub_rot<INV>(csub(y0[0], y0[2]), csub(y0[1], y0[3]));
+        x13 = sub_rot<INV>(csub(y1[0], y1[2]), csub(y1[1], y1[3]));
+        x14 = sub_rot<INV>(sub_rot<INV>(y2[0], y2[2]), sub_rot<INV>(y2[1], y2[3]));
+        x15 = sub_rot<INV>(sub_rot<INV>(y3[0], y3[2]), csub(y3[1], y3[3]));
+    }
 };
 
 constexpr int kTwiddleN = 4096;   // table holds exp(-2*pi*i*m/4096), m < 4096
@@ -381,14 +403,15 @@ struct BlockFFT {
 
     // `active` lets a workgroup wider than NT threads run the transform on its first
     // NT threads: the others skip the arithmetic but still meet every barrier.
-    // LAST2 (radix 16 only): the caller needs just X[tid + 14*NT] and X[tid + 15*NT];
-    // they are returned in v[14], v[15], every other v[] is then unspecified.
+    // KEEP = 2 / 4 (radix 16 only): the caller needs just the last 2 / 4 of the 16 outputs,
+    // X[tid + r*NT] for r >= 14 / r >= 12; they are returned in v[r], every other v[] is then
+    // unspecified.  KEEP = 0: everything.
     // `hook(p)` runs right after the barrier that closes pass p (p < PASSES-1): a place
     // for the caller to slip independent work (e.g. a couple of global loads) into the
     // transform's instruction stream.
     struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-    template <class TW, bool LAST2 = false, class Hook = NoHook>
+    template <class TW, int KEEP = 0, class Hook = NoHook>
     __device__ static __forceinline__ void run(cf (&v)[R], cf* __restrict__ ldsA,
                                                cf* __restrict__ ldsB, const TW& tws, int tid,
                                                bool active = true, Hook hook = Hook()) {
@@ -422,11 +445,18 @@ struct BlockFFT {
                 }
                 cf* tmp = buf; buf = other; other = tmp;
             }
-            if constexpr (LAST2 && R == 16) {
+            if constexpr (KEEP != 0 && R == 16) {
+                static_assert(KEEP == 2 || KEEP == 4, "KEEP is 0, 2 or 4");
                 if (p == PASSES - 1) {
                     if (active) {
-                        cf x14, x15;
-                        Butterfly<R, INV>::run_last2(v, x14, x15);
+                        cf x12, x13, x14, x15;
+                        if constexpr (KEEP == 2) {
+                            Butterfly<R, INV>::run_last2(v, x14, x15);
+                        } else {
+                            Butterfly<R, INV>::run_last4(v, x12, x13, x14, x15);
+                            v[12] = x12;
+                            v[13] = x13;
+                        }
                         v[14] = x14;
                         v[15] = x15;
                     }

@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -296,7 +297,7 @@ __device__ __forceinline__ void conv_one_buffer(
             cf zpb[16];
             partner_exchange<kNB, 16, true>(zb, zpb, X, tid);
             spectral_product<kNB, 16>(zb, zpb, cb, tid);
-            FBi::template run<typename FB::Twiddles, true>(zb, Y, X, twb, tid);   // last reads X; only [14],[15]
+            FBi::template run<typename FB::Twiddles, 2>(zb, Y, X, twb, tid);   // last reads X; only [14],[15]
             ya0 += zb[14].x; yb0 += zb[14].y;
             ya1 += zb[15].x; yb1 += zb[15].y;
         }
@@ -350,6 +351,174 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     conv_one_buffer<STREAM, TAIL, ABL>(in, out, hist, pmA, pmB, tw, T, head, lds);
 }
 
+// ---- split roles: near and far partitions on different workgroups ---------------------------
+// The same convolution with the taps cut so that no workgroup runs a short and a long transform
+// one after the other (that chain — first data, near transform, far transform, store — is what a
+// launch of conv_overlap_save_kernel lasts):
+//   A   taps [0,512)       N=1024, window [block k-1 | block k]
+//   A2  taps [512,1024)    N=1024, window [block k-2 | block k-1]; its spectral product joins
+//                          A's before ONE inverse
+//   F   taps [1024,4096)   N=4096, window [block k-7 .. block k]; keeps its last 1024 outputs,
+//                          which are blocks k+1 and k+2 (taps >= 1024 cannot reach further), and
+//                          parks them in a four-slot carry ring, slot = block & 3.
+// F therefore runs for a channel pair every OTHER buffer, one buffer ahead of its use.  Two
+// channel pairs form a duo with two workgroups on one CU (blockIdx b and b + grid/2):
+//   near workgroup: A and A2 of BOTH pairs, every launch — four 1024-point transforms held one
+//       per wave (no workgroup barrier but one), then the two inverses on waves 0 and 2; adds the
+//       parked far share of block k, writes the output and the history ring;
+//   far workgroup: F of pair 0 on even launches, of pair 1 on odd launches.
+// Nothing in a launch waits for anything else in it.  Bytes per launch: 37 MB instead of 44 MB.
+struct ConvSplit {
+    const float4* pmA2;    // [pairs][kBinsA]   taps [512,1024)
+    const float4* pmF;     // [pairs][kBinsB]   taps [1024,4096)
+    cf* carry;             // [pairs][4][512]   F's outputs, slot = block & 3
+    int debug;             // timing experiments (GAB_CONV_SPLIT_DEBUG): 1 near workgroups exit, 4 far workgroups exit
+};
+
+constexpr int kCarrySlots = 4;
+using PadA16 = fft::Pad<16>;
+constexpr int kWaveImg = PadA16::size(kNA);     // LDS image of one wave-held 1024-point transform
+
+__device__ __forceinline__ void conv_split_buffer(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head,
+    cf* __restrict__ lds) {
+    const int tid = threadIdx.x;
+    const int duos = gridDim.x / 2;
+    const bool far = (int)blockIdx.x >= duos;                         // uniform over the workgroup
+    const int d = xcd_contiguous(far ? blockIdx.x - duos : blockIdx.x, duos);
+
+    if (far) {
+        if (sp.debug & 4) return;
+        // ---- F of one pair: window = the seven newest blocks of the ring + the new block
+        const int q = 2 * d + (head & 1);
+        const int ta = 2 * q, tb = ta + 1;
+        const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const cp = sp.carry + (size_t)q * kCarrySlots * kB;
+        using FB = fft::BlockFFT<kNB, 16, false>;
+        using FBi = fft::BlockFFT<kNB, 16, true>;
+        cf* const X = lds;
+        cf* const Y = lds + kLdsHalf;
+        cf zb[16];
+        typename FB::Bases twb_base;
+        {
+            const float* xa = in + (size_t)ta * kB;
+            const float* xb = in + (size_t)tb * kB;
+            zb[14] = mk(xa[tid], xb[tid]);
+            zb[15] = mk(xa[tid + kThreads], xb[tid + kThreads]);
+        }
+        FB::load_twiddles(twb_base, tw, tid);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 14; ++r)                                  // blocks k-7 .. k-1, oldest first
+            zb[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid];
+        __builtin_amdgcn_sched_barrier(0);
+        float4 cb[16];
+        load_spectra<kNB, 16>(cb, sp.pmF + (size_t)q * kBinsB, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        typename FB::Twiddles twb;
+        FB::expand_twiddles(twb_base, twb);
+        FB::run(zb, X, Y, twb, tid);
+        cf zpb[16];
+        partner_exchange<kNB, 16, true>(zb, zpb, X, tid);
+        spectral_product<kNB, 16>(zb, zpb, cb, tid);
+        FBi::template run<typename FB::Twiddles, 4>(zb, Y, X, twb, tid);     // only [12..15]
+        cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;            // block k+1
+        cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;            // block k+2
+        c1[tid] = zb[12];
+        c1[tid + kThreads] = zb[13];
+        c2[tid] = zb[14];
+        c2[tid + kThreads] = zb[15];
+        return;
+    }
+
+    if (sp.debug & 1) return;
+    // ---- near: wave w holds one 1024-point transform: pair (w >> 1) of the duo, window w & 1
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = 2 * d + (w >> 1);
+    const int ta = 2 * q, tb = ta + 1;
+    const bool second = (w & 1) != 0;
+    cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+    cf* const img = lds + w * kWaveImg;
+    const int s1 = ((head + kSlots - 1) & (kSlots - 1)) * kB;         // block k-1
+    const int s2 = ((head + kSlots - 2) & (kSlots - 1)) * kB;         // block k-2
+    using WF = fft::WaveFFT1024<false>;
+    using WFi = fft::WaveFFT1024<true>;
+
+    cf z[16];
+    if (!second) {
+        const float* xa = in + (size_t)ta * kB;
+        const float* xb = in + (size_t)tb * kB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[8 + j] = mk(xa[lane + 64 * j], xb[lane + 64 * j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = hp[s1 + lane + 64 * j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[8 + j] = hp[s1 + lane + 64 * j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 c[16];
+    load_spectra<kNA, 16>(c, (second ? sp.pmA2 : pmA) + (size_t)q * kBinsA, lane);
+    WF::Twiddles t;
+    WF::load_twiddles(t, tw, lane);
+    if (!second) {                                                    // the new block enters the ring
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = z[8 + j];
+    }
+    WF::run(z, img, t, lane);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    {
+        cf zp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+        spectral_product<kNA, 16>(z, zp, c, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (second) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+    }
+    __syncthreads();
+    if (second) return;
+    {
+        const cf* const other = img + kWaveImg;                       // the A2 transform of the same pair
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = fft::cadd(z[r], other[rb + 68 * r]);
+    }
+    const cf* const cy = sp.carry + ((size_t)q * kCarrySlots + (head & (kCarrySlots - 1))) * kB;
+    cf park[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) park[j] = cy[lane + 64 * j];
+    WFi::run(z, img, t, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float* o = out + (size_t)T * (lane + 64 * j) + ta;
+        *reinterpret_cast<float2*>(o) = make_float2(z[8 + j].x + park[j].x, z[8 + j].y + park[j].y);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalf];
+    conv_split_buffer(in, out, hist, pmA, sp, tw, T, head, lds);
+}
+
+// Under its own name for buffers in pinned host memory (see conv_overlap_save_host_io_kernel).
+__global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalf];
+    conv_split_buffer(in, out, hist, pmA, sp, tw, T, head, lds);
+}
+
 // The same kernel under its own name for buffers that live in pinned host memory (the kernel then
 // moves them over the link itself): such launches run at link speed, and profilers average per
 // kernel name — this keeps them out of the figures of the HBM-resident launches.
@@ -389,10 +558,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
                                        (head + nb) & (kSlots - 1), lds);
 }
 
-// IR bank -> (P, M) spectra of both partitions.  d_ir is T x L track-major.
+// IR bank -> (P, M) spectra of a near (512 taps from offA) and a far (taps from offB) partition.
+// d_ir is T x L track-major.
 __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
     const float* __restrict__ ir, float4* __restrict__ pmA, float4* __restrict__ pmB,
-    const cf* __restrict__ tw, int T, int L) {
+    const cf* __restrict__ tw, int T, int L, int offA, int offB) {
     __shared__ cf lds[2 * kLdsHalf];
     cf* const lds0 = lds;
     cf* const lds1 = lds + kLdsHalf;
@@ -415,10 +585,10 @@ __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
                            0.5f * scale * (Ha.x - Hb.x), 0.5f * scale * (Ha.y - Hb.y));
     };
 
-    {   // partition A: taps [0,512) zero-padded to 1024
+    {   // near partition: taps [offA, offA+512) zero-padded to 1024
         cf z[4], zp[4];
-        z[0] = tap(tid);
-        z[1] = tap(tid + kThreads);
+        z[0] = tap(offA + tid);
+        z[1] = tap(offA + tid + kThreads);
         z[2] = mk(0.0f, 0.0f);
         z[3] = mk(0.0f, 0.0f);
         fft::BlockFFT<kNA, 4, false>::Twiddles t;
@@ -432,12 +602,12 @@ __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
         }
     }
     __syncthreads();
-    if (pmB != nullptr) {   // partition B: taps [512, 512+3584) zero-padded to 4096
+    if (pmB != nullptr) {   // far partition: taps [offB, 4096) zero-padded to 4096
         cf z[16], zp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int m = tid + r * kThreads;
-            z[r] = (m < kNB - kB) ? tap(kB + m) : mk(0.0f, 0.0f);
+            z[r] = (m < kNB - offB) ? tap(offB + m) : mk(0.0f, 0.0f);
         }
         fft::BlockFFT<kNB, 16, false>::Twiddles t;
         fft::BlockFFT<kNB, 16, false>::load_twiddles(t, tw, tid);
@@ -454,9 +624,6 @@ __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
 // Batched 1024-point R2C (cuda/bench_fft.cu:63,105): two tracks per complex transform,
 // one transform per WAVE (64 lanes x 16 values, three passes, exchanges private to the
 // wave: no workgroup barrier anywhere), four waves per workgroup.
-using PadA16 = fft::Pad<16>;
-constexpr int kWaveImg = PadA16::size(kNA);
-
 __global__ __launch_bounds__(kThreads) void fft_r2c_1024_kernel(
     const float* __restrict__ in, float2* __restrict__ out, const cf* __restrict__ tw, int T) {
     __shared__ cf lds[4 * kWaveImg];
@@ -550,6 +717,16 @@ struct gab_conv_plan {
     int hlen = 0;
     size_t spectra_bytes = 0, history_bytes = 0;
     const gab::fft::cf* tw = nullptr;
+    // split roles (conv_split_kernel): its spectra and the carry ring.  `split_live`: the carry
+    // ring holds what the next launch expects — true from a reset until something else moves the
+    // history ring.
+    bool split = false;
+    float4* pmA2 = nullptr;
+    float4* pmF = nullptr;
+    gab::fft::cf* carry = nullptr;
+    size_t carry_bytes = 0;
+    bool split_live = false;
+    bool fresh = true;        // nothing has run since the last reset
 };
 
 extern "C" {
@@ -575,6 +752,17 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
                 p->history_bytes = sizeof(float) * (size_t)p->pairs * 2 * gab::kSlots * gab::kB;
                 GAB_HIP_CHECK(hipMalloc(&p->hist, p->history_bytes));
                 GAB_HIP_CHECK(hipMemset(p->hist, 0, p->history_bytes));
+                const char* scheme = getenv("GAB_CONV_SCHEME");
+                const bool can_split = ir_len > 2 * gab::kB && (tracks % 4) == 0;
+                p->split = can_split && !(scheme && std::string(scheme) == "classic");
+                if (can_split) {
+                    GAB_HIP_CHECK(hipMalloc(&p->pmA2, a));
+                    GAB_HIP_CHECK(hipMalloc(&p->pmF, b));
+                    p->carry_bytes = sizeof(gab::fft::cf) * (size_t)p->pairs * gab::kCarrySlots * gab::kB;
+                    GAB_HIP_CHECK(hipMalloc(&p->carry, p->carry_bytes));
+                    GAB_HIP_CHECK(hipMemset(p->carry, 0, p->carry_bytes));
+                    p->split_live = p->split;
+                }
             } else {
                 int blocks = (ir_len - 1 + bufsize - 1) / bufsize;
                 p->hlen = (blocks < 1 ? 1 : blocks) * bufsize;
@@ -602,6 +790,9 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->hist) (void)hipFree(p->hist);
     if (p->hist_alt) (void)hipFree(p->hist_alt);
     if (p->ir_copy) (void)hipFree(p->ir_copy);
+    if (p->pmA2) (void)hipFree(p->pmA2);
+    if (p->pmF) (void)hipFree(p->pmF);
+    if (p->carry) (void)hipFree(p->carry);
     delete p;
     return GAB_OK;
 }
@@ -613,9 +804,13 @@ int gab_conv_set_ir(gab_conv_plan* p, const float* d_ir, gab_stream_t stream) {
         if (p->fused) {
             // pmB is null when ir_len <= 512: the kernel then skips partition B
             gab::conv_ir_spectra_kernel<<<p->pairs, gab::kThreads, 0, s>>>(
-                d_ir, p->pmA, p->pmB, p->tw, p->tracks, p->ir_len);
+                d_ir, p->pmA, p->pmB, p->tw, p->tracks, p->ir_len, 0, gab::kB);
+            if (p->pmF)
+                gab::conv_ir_spectra_kernel<<<p->pairs, gab::kThreads, 0, s>>>(
+                    d_ir, p->pmA2, p->pmF, p->tw, p->tracks, p->ir_len, gab::kB, 2 * gab::kB);
             int rc = gab::launch_status("conv_ir_spectra_kernel");
             if (rc) return rc;
+            if (!p->fresh) p->split_live = false;    // parked far shares were made with the old taps
         } else {
             GAB_HIP_CHECK(hipMemcpyAsync(p->ir_copy, d_ir, p->spectra_bytes,
                                          hipMemcpyDeviceToDevice, s));
@@ -626,11 +821,33 @@ int gab_conv_set_ir(gab_conv_plan* p, const float* d_ir, gab_stream_t stream) {
     });
 }
 
+int gab_conv_set_scheme(gab_conv_plan* p, int scheme) {
+    if (!p) return gab::bad_arg("gab_conv_set_scheme: null plan");
+    if (scheme != GAB_CONV_SCHEME_CLASSIC && scheme != GAB_CONV_SCHEME_SPLIT)
+        return gab::bad_arg("gab_conv_set_scheme: unknown scheme");
+    if (!p->fresh) return gab::bad_arg("gab_conv_set_scheme: only on a fresh plan (before the first buffer or right after a reset)");
+    if (scheme == GAB_CONV_SCHEME_SPLIT && !p->pmF)
+        return gab::bad_arg("gab_conv_set_scheme: the split scheme needs 512-sample buffers, 1025..4096 taps and a channel count divisible by 4");
+    const bool want = scheme == GAB_CONV_SCHEME_SPLIT;
+    p->split = want;
+    p->split_live = want;
+    return GAB_OK;
+}
+
+int gab_conv_get_scheme(const gab_conv_plan* p, int* scheme) {
+    if (!p || !scheme) return gab::bad_arg("gab_conv_get_scheme: null pointer");
+    *scheme = p->split ? GAB_CONV_SCHEME_SPLIT : GAB_CONV_SCHEME_CLASSIC;
+    return GAB_OK;
+}
+
 int gab_conv_reset(gab_conv_plan* p, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_conv_reset: null plan");
         GAB_HIP_CHECK(hipMemsetAsync(p->hist, 0, p->history_bytes, gab::as_stream(stream)));
         p->head = 0;
+        if (p->carry) GAB_HIP_CHECK(hipMemsetAsync(p->carry, 0, p->carry_bytes, gab::as_stream(stream)));
+        p->split_live = p->split;
+        p->fresh = true;
         return GAB_OK;
     });
 }
@@ -647,6 +864,22 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
         if (p->fused) {
             dim3 grid(p->pairs), block(gab::kThreads);
 #define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head
+            if (streaming) p->fresh = false;
+            if (streaming && p->split && p->split_live) {
+                static const int dbg = getenv("GAB_CONV_SPLIT_DEBUG") ? atoi(getenv("GAB_CONV_SPLIT_DEBUG")) : 0;
+                gab::ConvSplit sp{p->pmA2, p->pmF, p->carry, dbg};
+                if (mode == GAB_CONV_STREAMING_HOST_IO)
+                    gab::conv_split_host_io_kernel<<<grid, block, 0, s>>>(d_in, d_out, p->hist, p->pmA, sp, p->tw,
+                                                                         p->tracks, p->head);
+                else
+                    gab::conv_split_kernel<<<grid, block, 0, s>>>(d_in, d_out, p->hist, p->pmA, sp, p->tw,
+                                                                 p->tracks, p->head);
+                int rc = gab::launch_status("conv_split_kernel");
+                if (rc) return rc;
+                p->head = (p->head + 1) & (gab::kSlots - 1);
+                return GAB_OK;
+            }
+            if (streaming) p->split_live = false;     // the history ring moves on without the carry ring
             if (mode == GAB_CONV_STREAMING_HOST_IO) {
                 if (p->tail) gab::conv_overlap_save_host_io_kernel<true><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
                 else gab::conv_overlap_save_host_io_kernel<false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
@@ -699,6 +932,8 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
             int rc = gab::launch_status("conv_batch_kernel");
             if (rc) return rc;
             p->head = (p->head + n_buffers) & (gab::kSlots - 1);
+            p->split_live = false;
+            p->fresh = false;
             return GAB_OK;
         }
         // other shapes: one buffer at a time

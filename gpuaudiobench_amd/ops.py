@@ -136,10 +136,23 @@ def fft_r2c_1024(x, tracks):
 class ConvPlan:
     """Conv1DAccelBenchmark's device side: spectra bank + history + process()."""
 
-    def __init__(self, tracks, bufsize, ir_len):
+    def __init__(self, tracks, bufsize, ir_len, scheme=None):
+        """scheme: None (the library's default for this shape), "classic" or "split"
+        (gab_conv_set_scheme)."""
         self.tracks, self.bufsize, self.ir_len = tracks, bufsize, ir_len
         self._h = C.c_void_p()
         check(lib.gab_conv_create(C.byref(self._h), tracks, bufsize, ir_len))
+        if scheme is not None:
+            self.set_scheme(scheme)
+
+    def set_scheme(self, scheme):
+        check(lib.gab_conv_set_scheme(self._h, {"classic": 0, "split": 1}[scheme]))
+
+    @property
+    def scheme(self):
+        v = C.c_int(0)
+        check(lib.gab_conv_get_scheme(self._h, C.byref(v)))
+        return "split" if v.value == 1 else "classic"
 
     def set_ir(self, ir):
         assert ir.numel() == self.tracks * self.ir_len

@@ -138,6 +138,19 @@ typedef struct gab_conv_plan gab_conv_plan;
 
 #define GAB_CONV_STATELESS 0  /* reference semantics: zero history each call  */
 #define GAB_CONV_STREAMING 1  /* overlap-save with carried history            */
+/* How a streaming plan cuts the taps (gab_conv_set_scheme; default SPLIT where the shape allows:
+ * 512-sample buffers, 1025..4096 taps, channel count divisible by 4; GAB_CONV_SCHEME=classic in
+ * the environment makes CLASSIC the default):
+ *   CLASSIC  taps [0,512) + [512,4096), both transforms in one workgroup per channel pair;
+ *   SPLIT    taps [0,512) + [512,1024) + [1024,4096): the far partition runs for a pair every
+ *            other buffer, one buffer ahead, on its own workgroups (conv_split_kernel).  Same
+ *            convolution, different rounding: results agree to ~1e-7 of the peak, not bit for bit.
+ * gab_conv_process_batch and gab_conv_process_windowed always use the CLASSIC cut; after a batch
+ * call a SPLIT plan continues with CLASSIC launches until the next gab_conv_reset.              */
+#define GAB_CONV_SCHEME_CLASSIC 0
+#define GAB_CONV_SCHEME_SPLIT 1
+int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);   /* fresh plans only (before the first buffer / after reset) */
+int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);
 #define GAB_CONV_STREAMING_HOST_IO 2  /* the same, d_in / d_out in pinned host memory: identical kernel
                                        * under its own name, so that link-speed launches do not
                                        * mix into per-kernel profiles of the HBM-resident ones    */

@@ -163,11 +163,20 @@ def test_conv_accel_reference_semantics(gab, orc, L, T):
     plan.set_ir(dev(ir))
     y0 = host(plan.process(dev(x), mode=gab.CONV_STATELESS))
     assert peak_err(y0, ref) <= TOL
-    # a freshly reset streaming plan gives the same first buffer
-    plan.reset()
-    y1 = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
-    assert peak_err(y1, ref) <= TOL
-    assert np.array_equal(bits(y0), bits(y1))
+    # a freshly reset streaming plan gives the same first buffer: to the bit with the classic cut
+    # of the taps, to rounding with the split one (where the shape has it)
+    for scheme in ("classic", "split"):
+        plan.reset()
+        try:
+            plan.set_scheme(scheme)
+        except gab.GabError:
+            assert scheme == "split" and not (L > 1024 and T % 4 == 0)
+            continue
+        assert plan.scheme == scheme
+        y1 = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
+        assert peak_err(y1, ref) <= TOL
+        if scheme == "classic":
+            assert np.array_equal(bits(y0), bits(y1))
     plan.close()
 
 
@@ -294,11 +303,11 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
 
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (5, 512, 2000, 3), (16, 512, 512, 4), (3, 256, 700, 5)])
 def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
-    """gab_conv_process_batch: n buffers in one launch walk the same history as n launches —
-    same bits — including across two batches and for shapes that take the fallback."""
+    """gab_conv_process_batch: n buffers in one launch walk the same history as n launches of the
+    classic cut — same bits — including across two batches and for shapes that take the fallback."""
     import torch
     ir = dev(orc.conv_accel_ir(L, T))
-    a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L)
     a.set_ir(ir)
     b.set_ir(ir)
     x = np.concatenate([orc.noise(T * B, seed=60 + i) for i in range(2 * n)])
@@ -310,6 +319,52 @@ def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
     with pytest.raises(gab.GabError):
         lib_rc = gab.lib.gab_conv_process_batch(b._h, None, None, 1, None)
         gab.check(lib_rc)
+    a.close()
+    b.close()
+
+
+def test_conv_accel_split_and_classic_streams_agree(gab, orc):
+    """The split cut (far partition every other buffer, one buffer ahead, on its own workgroups)
+    and the classic cut are the same convolution: 30 buffers agree to rounding, against each other
+    and against the float64 direct form; a batch call in the middle of a split stream (which
+    moves the history ring without the carry ring) is followed by classic launches that stay
+    correct, and a reset brings the split launches back."""
+    import torch
+    T, B, L = 64, 512, 4096
+    ir = orc.conv_accel_ir(L, T)
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="split")
+    assert (a.scheme, b.scheme) == ("classic", "split")
+    a.set_ir(dev(ir))
+    b.set_ir(dev(ir))
+    hist = np.zeros(T * L, np.float32)
+    xs = [orc.noise(T * B, seed=900 + i) for i in range(30)]
+    peak = 0.0
+    for i, x in enumerate(xs):
+        ref = orc.conv_accel_stream(x, ir, hist, L, B, T, f64=True)
+        peak = max(peak, float(np.abs(ref).max()))
+        if i == 20:                                   # two buffers through the batch entry point
+            continue
+        if i == 21:
+            yb = host(b.process_batch(dev(np.concatenate([xs[20], xs[21]])), 2))[T * B:]
+            ya = host(a.process_batch(dev(np.concatenate([xs[20], xs[21]])), 2))[T * B:]
+        else:
+            ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+            yb = host(b.process(dev(x), mode=gab.CONV_STREAMING))
+        if i >= 8:
+            assert np.abs(ya - ref).max() <= 1e-5 * peak, i
+            assert np.abs(yb - ref).max() <= 1e-5 * peak, i
+            assert np.abs(ya - yb).max() <= 2e-6 * peak, i
+        if i >= 21:
+            assert np.array_equal(bits(ya), bits(yb)), i          # b runs classic launches now
+    with pytest.raises(gab.GabError):
+        b.set_scheme("classic")                       # only on a fresh plan
+    b.reset()
+    a.reset()
+    assert b.scheme == "split"
+    y0 = host(b.process(dev(xs[0]), mode=gab.CONV_STREAMING))
+    assert peak_err(y0, orc.conv_accel(xs[0], ir, L, B, T)) <= TOL
+    with pytest.raises(gab.GabError):
+        gab.ConvPlan(6, B, L, scheme="split")         # needs a channel count divisible by 4
     a.close()
     b.close()
 
@@ -338,12 +393,12 @@ def test_conv_accel_long_stream_does_not_drift(gab, orc):
 @pytest.mark.parametrize("T,L", [(64, 4096), (5, 1000), (3, 4096)])
 def test_conv_accel_windowed_stateless_equals_ring(gab, orc, T, L):
     """gab_conv_process_windowed: history = the caller's last eight input buffers (zeros before the
-    stream began); no plan state.  Same bits as the ring-based streaming path, also when the calls
-    alternate between two streams."""
+    stream began); no plan state.  Same bits as the ring-based streaming path with the classic
+    cut, also when the calls alternate between two streams."""
     import torch
     B = 512
     ir = dev(orc.conv_accel_ir(L, T))
-    a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L)
     a.set_ir(ir)
     b.set_ir(ir)
     xs = [dev(orc.noise(T * B, seed=400 + i)) for i in range(14)]
