@@ -179,6 +179,7 @@ def main():
     torch.cuda.synchronize()
     batch_us = eb0.elapsed_time(eb1) * 1e3 / (nrep * nb)
     del xb, yb
+    plan.reset()          # a batch call moves the history ring with the classic cut; back to the plan's own
 
     # ---- pipelined mode (not `value`): the stateless kernel (history = the caller's last eight
     # input buffers), consecutive buffers alternating between two streams, so the device overlaps
@@ -229,6 +230,7 @@ def main():
             if i >= 20:
                 zc.append((time.perf_counter() - t1) * 1e6)
         zc = np.array(zc)
+        plan.reset()      # host-io launches use the classic cut; back to the plan's own
 
     # ---- the same round trip under DAW pacing: one buffer per 512/48000 s slot, device idle in
     # between (the Metal port's DAWSimulator) --------------------------------------
@@ -255,7 +257,8 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("conv_overlap_save_kernel_bytes_per_launch")
+            traffic = json.load(open(pmc_file)).get(
+                "conv_split_kernel_bytes_per_launch" if plan.scheme == "split" else "conv_overlap_save_kernel_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -278,7 +281,7 @@ def main():
                         % (L, T, B, FS, "; configs[4]-style channel sharding, %d channels total" % T_total
                            if world > 1 else ""),
             "taps": L, "channels_per_gpu": T, "channels_total": T_total, "buffer_size": B, "fs": FS,
-            "mode": "streaming",
+            "mode": "streaming", "tap_cut": plan.scheme,
             "realtime_factor": (world * args.steps / elapsed) * B / FS,
             "p50_round_trip_us": float(np.percentile(rt, 50)),
             "p95_round_trip_us": float(np.percentile(rt, 95)),
@@ -297,7 +300,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "conv_overlap_save_kernel<true,true>",
+            "kernel": "conv_split_kernel" if plan.scheme == "split" else "conv_overlap_save_kernel<true,true>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

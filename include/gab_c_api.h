@@ -145,8 +145,9 @@ typedef struct gab_conv_plan gab_conv_plan;
  *   SPLIT    taps [0,512) + [512,1024) + [1024,4096): the far partition runs for a pair every
  *            other buffer, one buffer ahead, on its own workgroups (conv_split_kernel).  Same
  *            convolution, different rounding: results agree to ~1e-7 of the peak, not bit for bit.
- * gab_conv_process_batch and gab_conv_process_windowed always use the CLASSIC cut; after a batch
- * call a SPLIT plan continues with CLASSIC launches until the next gab_conv_reset.              */
+ * gab_conv_process_batch, gab_conv_process_windowed and host-io launches always use the CLASSIC
+ * cut; after a batch or host-io call a SPLIT plan continues with CLASSIC launches until the next
+ * gab_conv_reset.                                                                                */
 #define GAB_CONV_SCHEME_CLASSIC 0
 #define GAB_CONV_SCHEME_SPLIT 1
 int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);   /* fresh plans only (before the first buffer / after reset) */
