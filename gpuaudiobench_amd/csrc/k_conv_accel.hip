@@ -26,6 +26,10 @@
 // P = (Ha+Hb)/2, M = (Ha-Hb)/2 (1/N folded in); real(ifft W) = y_a,
 // imag = y_b.  One workgroup (256 threads) = one channel pair; the 4096-point
 // transform is three radix-16 passes, the 1024-point one five radix-4 passes.
+//
+// Streaming plans at the headline shape use a different cut of the same taps,
+// conv_split_kernel below ("split roles"): taps [0,512) + [512,1024) on one
+// workgroup, taps [1024,4096) every other buffer and one buffer ahead on another.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
