@@ -391,8 +391,20 @@ __device__ __forceinline__ void conv_split_buffer(
     const int duos = gridDim.x / 2;
     // near workgroups first in dispatch order, equal priority: measured best (far first 10.7 us,
     // far at raised priority 10.7, near at raised priority 9.4, as is 9.4)
-    const bool far = (int)blockIdx.x >= duos;                         // uniform over the workgroup
-    const int d = xcd_contiguous(far ? blockIdx.x - duos : blockIdx.x, duos);
+    // Roles alternate in runs of 256 workgroups (one per CU), so that whatever part of a large
+    // grid is resident holds as many near as far workgroups, one of each per CU; a 512-workgroup
+    // grid is simply near half, far half.  Grids that are not a multiple of 512: halves.
+    bool far;                                                         // uniform over the workgroup
+    int slot;                                                         // index within the role
+    if ((gridDim.x & 511) == 0) {
+        const int run = blockIdx.x >> 8;
+        far = (run & 1) != 0;
+        slot = (run >> 1) * 256 + (blockIdx.x & 255);
+    } else {
+        far = (int)blockIdx.x >= duos;
+        slot = far ? blockIdx.x - duos : blockIdx.x;
+    }
+    const int d = xcd_contiguous(slot, duos);
 
     if (far) {
         if (sp.debug & 4) return;
