@@ -975,8 +975,11 @@ int gab_conv_process_windowed(gab_conv_plan* p, const float* d_in, const float* 
 
 int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* history) {
     if (!p) return gab::bad_arg("gab_conv_state_bytes: null plan");
-    if (spectra) *spectra = p->spectra_bytes;
-    if (history) *history = p->history_bytes;
+    // everything resident for the plan: a plan that can use the split cut holds both sets of spectra
+    // (classic for batch / windowed / host-io launches) and the carry ring beside the history ring
+    const size_t bank = p->pmF ? sizeof(float4) * (size_t)p->pairs * (gab::kBinsA + gab::kBinsB) : 0;
+    if (spectra) *spectra = p->spectra_bytes + bank;
+    if (history) *history = p->history_bytes + p->carry_bytes;
     return GAB_OK;
 }
 
