@@ -3,6 +3,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 os.environ["GAB_CONV_ABLATE"] = "6"
+os.environ["GAB_CONV_SCHEME"] = "classic"      # the stamps live in the classic kernel
 import gpuaudiobench_amd as gab
 T, B, L = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 512, 4096
 plan = gab.ConvPlan(T, B, L)
