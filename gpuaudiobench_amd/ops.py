@@ -192,6 +192,16 @@ class ConvPlan:
         check(lib.gab_conv_process_windowed(self._h, _dev(x), ptrs, _dev(out), st))
         return out
 
+    def prepare(self, x, out, mode=CONV_STREAMING, stream=None):
+        """The ctypes arguments of process(), built once for a loop that cycles through a fixed set
+        of buffers; `launch(args)` then costs ~4 us of host time instead of ~7.5."""
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        return (self._h, _dev(x), _dev(out), mode, st)
+
+    @staticmethod
+    def launch(args):
+        check(lib.gab_conv_process(*args))
+
     def prepare_windowed(self, x, previous, out, stream):
         """The ctypes arguments of process_windowed, built once: a loop that cycles through a fixed
         set of buffers replays them with `launch_prepared` at ~4 us of host time per call."""
