@@ -356,6 +356,9 @@ def test_conv_accel_split_and_classic_streams_agree(gab, orc):
             assert np.abs(ya - yb).max() <= 2e-6 * peak, i
         if i >= 21:
             assert np.array_equal(bits(ya), bits(yb)), i          # b runs classic launches now
+    # prepared arguments (what bench.py's timed loop uses) are the same call
+    args = b.prepare(dev(xs[0]), torch.empty(T * B, device="cuda"))
+    b.launch(args)
     with pytest.raises(gab.GabError):
         b.set_scheme("classic")                       # only on a fresh plan
     b.reset()
