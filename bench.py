@@ -208,6 +208,33 @@ def main():
     torch.cuda.synchronize()
     pipe_us = (time.perf_counter() - t1) * 1e6 / n_pipe
 
+    # ---- channel ranges on two streams (not `value`): the same buffers, each launched as two
+    # halves of the channels on two streams.  Channels are independent, so every stream is its own
+    # chain of dependent launches and the chains overlap each other's kernel boundaries.  Same bits.
+    two_us = None
+    if plan.scheme == "split" and T % 8 == 0:
+        plan.reset()
+        halves = [(0, T // 2), (T // 2, T // 2)]
+        range_args = [[plan.prepare_range(x, out, lo, n, side[j]) for j, (lo, n) in enumerate(halves)]
+                      for x in inputs]
+        launch_range, advance = plan.launch_range, plan.advance
+
+        def step2(i):
+            for a in range_args[i % N_INPUT_BUFFERS]:
+                launch_range(a)
+            advance()
+
+        for i in range(200):
+            step2(i)
+        torch.cuda.synchronize()
+        n_two = min(args.steps, 3000)
+        t1 = time.perf_counter()
+        for i in range(n_two):
+            step2(i)
+        torch.cuda.synchronize()
+        two_us = (time.perf_counter() - t1) * 1e6 / n_two
+        plan.reset()
+
     # ---- p50 round trip: pinned host -> HBM -> kernel -> HBM -> pinned host ----------
     h_in = torch.from_numpy(gab.harness.noise(T * B, seed=7)).pin_memory()
     h_out = torch.empty(T * B, dtype=torch.float32).pin_memory()
@@ -301,6 +328,9 @@ def main():
                                                  "alg_GBps": algorithmic_bytes(T, B, L) / batch_us / 1e3},
             "pipelined_two_streams_stateless_kernel": {"us_per_buffer": pipe_us, "buffers_per_sec": 1e6 / pipe_us,
                                                        "alg_GBps": algorithmic_bytes(T, B, L) / pipe_us / 1e3},
+            "channel_halves_on_two_streams": None if two_us is None else {
+                "us_per_buffer": two_us, "buffers_per_sec": 1e6 / two_us,
+                "alg_GBps": algorithmic_bytes(T, B, L) / two_us / 1e3},
             "ir_broadcast_ms": bcast_ms,
             "state_bytes": {"spectra": spectra_bytes, "history": history_bytes},
         },

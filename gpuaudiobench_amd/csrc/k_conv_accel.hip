@@ -928,6 +928,39 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
     });
 }
 
+// One buffer, a RANGE of the channels: the same launch as gab_conv_process on offset base pointers
+// (every per-channel array is laid out by channel pair; the output keeps the plan's full stride).
+// Channels are independent, so a caller may give disjoint ranges to different streams: each stream
+// is then its own chain of dependent launches, and the chains overlap each other's kernel
+// boundaries.  The ring position is the plan's: call gab_conv_advance once per buffer, after every
+// range of that buffer has been queued.
+int gab_conv_process_range(gab_conv_plan* p, const float* d_in, float* d_out, int first_channel,
+                           int n_channels, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!p || !d_in || !d_out) return gab::bad_arg("gab_conv_process_range: null argument");
+        if (!p->ir_set) return gab::bad_arg("gab_conv_process_range: gab_conv_set_ir has not been called");
+        if (!(p->split && p->split_live))
+            return gab::bad_arg("gab_conv_process_range: needs a plan on the split cut (see gab_conv_set_scheme)");
+        if (first_channel < 0 || n_channels <= 0 || (first_channel & 3) || (n_channels & 3) ||
+            first_channel + n_channels > p->tracks)
+            return gab::bad_arg("gab_conv_process_range: the range must lie inside the plan and start and end on multiples of 4 channels");
+        const size_t q0 = (size_t)first_channel / 2;
+        gab::ConvSplit sp{p->pmA2 + q0 * gab::kBinsA, p->pmF + q0 * gab::kBinsB,
+                          p->carry + q0 * gab::kCarrySlots * gab::kB, 0};
+        gab::conv_split_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, gab::as_stream(stream)>>>(
+            d_in + (size_t)first_channel * p->bufsize, d_out + first_channel,
+            p->hist + q0 * 2 * gab::kSlots * gab::kB, p->pmA + q0 * gab::kBinsA, sp, p->tw, p->tracks, p->head);
+        p->fresh = false;
+        return gab::launch_status("conv_split_kernel");
+    });
+}
+
+int gab_conv_advance(gab_conv_plan* p) {
+    if (!p) return gab::bad_arg("gab_conv_advance: null plan");
+    p->head = (p->head + 1) & (gab::kSlots - 1);
+    return GAB_OK;
+}
+
 int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, int n_buffers,
                            gab_stream_t stream) {
     return gab::guarded([&]() -> int {

@@ -192,6 +192,22 @@ class ConvPlan:
         check(lib.gab_conv_process_windowed(self._h, _dev(x), ptrs, _dev(out), st))
         return out
 
+    def process_range(self, x, out, first_channel, n_channels, stream=None):
+        """gab_conv_process_range: one buffer, channels [first, first + n) only; x / out are the
+        whole buffers.  Call advance() once per buffer after all its ranges are queued."""
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        check(lib.gab_conv_process_range(self._h, _dev(x), _dev(out), first_channel, n_channels, st))
+
+    def prepare_range(self, x, out, first_channel, n_channels, stream):
+        return (self._h, _dev(x), _dev(out), first_channel, n_channels, C.c_void_p(stream.cuda_stream))
+
+    @staticmethod
+    def launch_range(args):
+        check(lib.gab_conv_process_range(*args))
+
+    def advance(self):
+        check(lib.gab_conv_advance(self._h))
+
     def prepare(self, x, out, mode=CONV_STREAMING, stream=None):
         """The ctypes arguments of process(), built once for a loop that cycles through a fixed set
         of buffers; `launch(args)` then costs ~4 us of host time instead of ~7.5."""

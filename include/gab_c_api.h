@@ -150,6 +150,14 @@ typedef struct gab_conv_plan gab_conv_plan;
  * gab_conv_reset.                                                                                */
 #define GAB_CONV_SCHEME_CLASSIC 0
 #define GAB_CONV_SCHEME_SPLIT 1
+/* One buffer, a range of the channels (split cut only; first_channel and n_channels multiples of
+ * 4): the same launch on offset base pointers; d_in / d_out are the whole buffers.  Disjoint ranges
+ * may go to different streams — channels are independent, so each stream is its own chain of
+ * launches and the chains overlap each other's kernel boundaries.  gab_conv_advance moves the
+ * plan's ring position: once per buffer, after all its ranges have been queued.                 */
+int gab_conv_process_range(gab_conv_plan* plan, const float* d_in, float* d_out, int first_channel,
+                           int n_channels, gab_stream_t stream);
+int gab_conv_advance(gab_conv_plan* plan);
 int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);   /* fresh plans only (before the first buffer / after reset) */
 int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);
 #define GAB_CONV_STREAMING_HOST_IO 2  /* the same, d_in / d_out in pinned host memory: identical kernel

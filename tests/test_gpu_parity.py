@@ -372,6 +372,37 @@ def test_conv_accel_split_and_classic_streams_agree(gab, orc):
     b.close()
 
 
+def test_conv_accel_channel_ranges_on_two_streams(gab, orc):
+    """gab_conv_process_range: a buffer launched as two channel ranges on two streams is the same
+    computation as one launch — same bits — over a stream of buffers."""
+    import torch
+    T, B, L = 64, 512, 4096
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.empty(T * B, device="cuda") for _ in range(2)]
+    for i in range(12):
+        x = dev(orc.noise(T * B, seed=700 + i))
+        ya = host(a.process(x, mode=gab.CONV_STREAMING))
+        torch.cuda.synchronize()
+        yb = outs[i % 2]
+        b.process_range(x, yb, 0, 24, stream=s1)
+        b.process_range(x, yb, 24, 40, stream=s2)
+        b.advance()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(ya), bits(host(yb))), i
+    with pytest.raises(gab.GabError):
+        b.process_range(x, yb, 2, 8)                  # ranges start and end on multiples of 4
+    c = gab.ConvPlan(T, B, L, scheme="classic")
+    c.set_ir(ir)
+    with pytest.raises(gab.GabError):
+        c.process_range(x, yb, 0, 32)
+    for p in (a, b, c):
+        p.close()
+
+
 def test_conv_accel_long_stream_does_not_drift(gab, orc):
     """400 buffers (the 8-slot ring wraps 50 times; the only carried state is an exact copy of the
     input): the error against the float64 direct form stays where it was after the first window."""
