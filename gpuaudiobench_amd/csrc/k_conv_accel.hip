@@ -530,6 +530,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(
 }
 
 
+// Channel-range launches (gab_conv_process_range) under their own name: they carry a part of a
+// buffer each, and profilers average per kernel name.
+__global__ __launch_bounds__(kThreads, 2) void conv_split_range_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalf];
+    conv_split_buffer(in, out, hist, pmA, sp, tw, T, head, lds);
+}
+
 // The same kernel under its own name for buffers that live in pinned host memory (the kernel then
 // moves them over the link itself): such launches run at link speed, and profilers average per
 // kernel name — this keeps them out of the figures of the HBM-resident launches.
@@ -947,11 +956,11 @@ int gab_conv_process_range(gab_conv_plan* p, const float* d_in, float* d_out, in
         const size_t q0 = (size_t)first_channel / 2;
         gab::ConvSplit sp{p->pmA2 + q0 * gab::kBinsA, p->pmF + q0 * gab::kBinsB,
                           p->carry + q0 * gab::kCarrySlots * gab::kB, 0};
-        gab::conv_split_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, gab::as_stream(stream)>>>(
+        gab::conv_split_range_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, gab::as_stream(stream)>>>(
             d_in + (size_t)first_channel * p->bufsize, d_out + first_channel,
             p->hist + q0 * 2 * gab::kSlots * gab::kB, p->pmA + q0 * gab::kBinsA, sp, p->tw, p->tracks, p->head);
         p->fresh = false;
-        return gab::launch_status("conv_split_kernel");
+        return gab::launch_status("conv_split_range_kernel");
     });
 }
 
