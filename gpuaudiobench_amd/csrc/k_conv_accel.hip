@@ -964,6 +964,25 @@ int gab_conv_process_range(gab_conv_plan* p, const float* d_in, float* d_out, in
     });
 }
 
+// n_buffers consecutive buffers (input i = d_in[i % n_in]), each queued as n_ranges channel ranges
+// on their streams: the loop a native host would write around gab_conv_process_range /
+// gab_conv_advance, here so that an interpreted caller can keep several streams fed.
+int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in, float* d_out,
+                           const int* first_channel, const int* n_channels, const gab_stream_t* streams,
+                           int n_ranges, int n_buffers) {
+    if (!p || !d_in || !d_out || !first_channel || !n_channels || !streams)
+        return gab::bad_arg("gab_conv_stream_ranges: null argument");
+    if (n_in <= 0 || n_ranges <= 0 || n_buffers < 0) return gab::bad_arg("gab_conv_stream_ranges: counts must be positive");
+    for (int i = 0; i < n_buffers; ++i) {
+        for (int r = 0; r < n_ranges; ++r) {
+            int rc = gab_conv_process_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r], streams[r]);
+            if (rc) return rc;
+        }
+        gab_conv_advance(p);
+    }
+    return GAB_OK;
+}
+
 int gab_conv_advance(gab_conv_plan* p) {
     if (!p) return gab::bad_arg("gab_conv_advance: null plan");
     p->head = (p->head + 1) & (gab::kSlots - 1);

@@ -208,6 +208,17 @@ class ConvPlan:
     def advance(self):
         check(lib.gab_conv_advance(self._h))
 
+    def stream_ranges(self, inputs, out, ranges, streams, n_buffers):
+        """gab_conv_stream_ranges: n_buffers consecutive buffers (cycling through `inputs`), each
+        queued as the channel ranges [(first, count), ...] on the matching torch streams."""
+        n = len(ranges)
+        assert len(streams) == n
+        ins = (C.c_void_p * len(inputs))(*[_dev(t).value for t in inputs])
+        first = (C.c_int * n)(*[r[0] for r in ranges])
+        count = (C.c_int * n)(*[r[1] for r in ranges])
+        sts = (C.c_void_p * n)(*[s.cuda_stream for s in streams])
+        check(lib.gab_conv_stream_ranges(self._h, ins, len(inputs), _dev(out), first, count, sts, n, n_buffers))
+
     def prepare(self, x, out, mode=CONV_STREAMING, stream=None):
         """The ctypes arguments of process(), built once for a loop that cycles through a fixed set
         of buffers; `launch(args)` then costs ~4 us of host time instead of ~7.5."""

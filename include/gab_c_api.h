@@ -158,6 +158,11 @@ typedef struct gab_conv_plan gab_conv_plan;
 int gab_conv_process_range(gab_conv_plan* plan, const float* d_in, float* d_out, int first_channel,
                            int n_channels, gab_stream_t stream);
 int gab_conv_advance(gab_conv_plan* plan);
+/* The loop around the two calls above, for n_buffers consecutive buffers (input i = d_in[i % n_in],
+ * all into d_out): range r of every buffer goes to streams[r].                                   */
+int gab_conv_stream_ranges(gab_conv_plan* plan, const float* const* d_in, int n_in, float* d_out,
+                           const int* first_channel, const int* n_channels, const gab_stream_t* streams,
+                           int n_ranges, int n_buffers);
 int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);   /* fresh plans only (before the first buffer / after reset) */
 int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);
 #define GAB_CONV_STREAMING_HOST_IO 2  /* the same, d_in / d_out in pinned host memory: identical kernel

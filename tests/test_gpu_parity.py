@@ -393,6 +393,15 @@ def test_conv_accel_channel_ranges_on_two_streams(gab, orc):
         b.advance()
         torch.cuda.synchronize()
         assert np.array_equal(bits(ya), bits(host(yb))), i
+    # the library-side loop over buffers and ranges is the same sequence of calls
+    xs = [dev(orc.noise(T * B, seed=800 + i)) for i in range(3)]
+    a.reset()
+    b.reset()
+    for i in range(5):
+        ya = host(a.process(xs[i % 3], mode=gab.CONV_STREAMING))
+    b.stream_ranges(xs, yb, [(0, 32), (32, 32)], [s1, s2], 5)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(ya), bits(host(yb)))
     with pytest.raises(gab.GabError):
         b.process_range(x, yb, 2, 8)                  # ranges start and end on multiples of 4
     c = gab.ConvPlan(T, B, L, scheme="classic")
