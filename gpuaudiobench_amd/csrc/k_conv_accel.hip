@@ -34,8 +34,10 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -747,6 +749,26 @@ struct gab_conv_plan {
     size_t carry_bytes = 0;
     bool split_live = false;
     bool fresh = true;        // nothing has run since the last reset
+    // Ordering between gab_conv_reset (memsets on the caller's stream) and launches on OTHER streams
+    // (channel ranges): the reset waits for every stream that launched since the previous reset, and
+    // a stream's first launch after a reset waits for the reset's event.
+    int device = 0;
+    hipEvent_t reset_ev = nullptr;
+    hipStream_t reset_stream = nullptr;
+    bool reset_recorded = false;
+    std::vector<hipStream_t> used_streams;      // launched on since the last reset
+    std::vector<hipStream_t> ordered_streams;   // already wait for reset_ev
+    std::mutex order_mu;
+
+    // called before every launch on `s`
+    void order_after_reset(hipStream_t s) {
+        std::lock_guard<std::mutex> lock(order_mu);
+        if (std::find(used_streams.begin(), used_streams.end(), s) == used_streams.end()) used_streams.push_back(s);
+        if (!reset_recorded || s == reset_stream) return;
+        if (std::find(ordered_streams.begin(), ordered_streams.end(), s) != ordered_streams.end()) return;
+        GAB_HIP_CHECK(hipStreamWaitEvent(s, reset_ev, 0));
+        ordered_streams.push_back(s);
+    }
 };
 
 extern "C" {
@@ -759,6 +781,8 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
         auto* p = new gab_conv_plan;
         p->tracks = tracks; p->bufsize = bufsize; p->ir_len = ir_len;
         p->pairs = (tracks + 1) / 2;
+        GAB_HIP_CHECK(hipGetDevice(&p->device));
+        GAB_HIP_CHECK(hipEventCreateWithFlags(&p->reset_ev, hipEventDisableTiming));
         p->fused = (bufsize == gab::kB && ir_len <= gab::kNB);
         p->tail = ir_len > gab::kB;
         try {
@@ -813,6 +837,7 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->pmA2) (void)hipFree(p->pmA2);
     if (p->pmF) (void)hipFree(p->pmF);
     if (p->carry) (void)hipFree(p->carry);
+    if (p->reset_ev) (void)hipEventDestroy(p->reset_ev);
     delete p;
     return GAB_OK;
 }
@@ -863,9 +888,27 @@ int gab_conv_get_scheme(const gab_conv_plan* p, int* scheme) {
 int gab_conv_reset(gab_conv_plan* p, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_conv_reset: null plan");
-        GAB_HIP_CHECK(hipMemsetAsync(p->hist, 0, p->history_bytes, gab::as_stream(stream)));
+        hipStream_t s = gab::as_stream(stream);
+        {
+            // launches still in flight on other streams read the rings: the memsets go behind them
+            std::lock_guard<std::mutex> lock(p->order_mu);
+            for (hipStream_t u : p->used_streams) {
+                if (u == s) continue;
+                GAB_HIP_CHECK(hipEventRecord(p->reset_ev, u));
+                GAB_HIP_CHECK(hipStreamWaitEvent(s, p->reset_ev, 0));
+            }
+            p->used_streams.clear();
+            p->ordered_streams.clear();
+        }
+        GAB_HIP_CHECK(hipMemsetAsync(p->hist, 0, p->history_bytes, s));
         p->head = 0;
-        if (p->carry) GAB_HIP_CHECK(hipMemsetAsync(p->carry, 0, p->carry_bytes, gab::as_stream(stream)));
+        if (p->carry) GAB_HIP_CHECK(hipMemsetAsync(p->carry, 0, p->carry_bytes, s));
+        {
+            std::lock_guard<std::mutex> lock(p->order_mu);
+            GAB_HIP_CHECK(hipEventRecord(p->reset_ev, s));
+            p->reset_stream = s;
+            p->reset_recorded = true;
+        }
         p->split_live = p->split;
         p->fresh = true;
         return GAB_OK;
@@ -881,6 +924,7 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
             return gab::bad_arg("gab_conv_process: unknown mode");
         hipStream_t s = gab::as_stream(stream);
         const bool streaming = mode != GAB_CONV_STATELESS;
+        if (streaming) p->order_after_reset(s);
         if (p->fused) {
             dim3 grid(p->pairs), block(gab::kThreads);
 #define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head
@@ -943,44 +987,115 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
 // is then its own chain of dependent launches, and the chains overlap each other's kernel
 // boundaries.  The ring position is the plan's: call gab_conv_advance once per buffer, after every
 // range of that buffer has been queued.
+}  // extern "C"
+
+namespace {
+
+int check_range(const gab_conv_plan* p, const char* who, int first_channel, int n_channels) {
+    if (!(p->split && p->split_live))
+        return gab::bad_arg((std::string(who) + ": needs a plan on the split cut (see gab_conv_set_scheme)").c_str());
+    if (first_channel < 0 || n_channels <= 0 || (first_channel & 3) || (n_channels & 3) ||
+        first_channel + n_channels > p->tracks)
+        return gab::bad_arg((std::string(who) + ": the range must lie inside the plan and start and end on multiples of 4 channels").c_str());
+    return GAB_OK;
+}
+
+// the launch itself; `head` is the ring slot of this buffer
+int launch_range(gab_conv_plan* p, const float* d_in, float* d_out, int first_channel, int n_channels,
+                 int head, hipStream_t s) {
+    const size_t q0 = (size_t)first_channel / 2;
+    gab::ConvSplit sp{p->pmA2 + q0 * gab::kBinsA, p->pmF + q0 * gab::kBinsB,
+                      p->carry + q0 * gab::kCarrySlots * gab::kB, 0};
+    gab::conv_split_range_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, s>>>(
+        d_in + (size_t)first_channel * p->bufsize, d_out + first_channel,
+        p->hist + q0 * 2 * gab::kSlots * gab::kB, p->pmA + q0 * gab::kBinsA, sp, p->tw, p->tracks, head);
+    return gab::launch_status("conv_split_range_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
 int gab_conv_process_range(gab_conv_plan* p, const float* d_in, float* d_out, int first_channel,
                            int n_channels, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p || !d_in || !d_out) return gab::bad_arg("gab_conv_process_range: null argument");
         if (!p->ir_set) return gab::bad_arg("gab_conv_process_range: gab_conv_set_ir has not been called");
-        if (!(p->split && p->split_live))
-            return gab::bad_arg("gab_conv_process_range: needs a plan on the split cut (see gab_conv_set_scheme)");
-        if (first_channel < 0 || n_channels <= 0 || (first_channel & 3) || (n_channels & 3) ||
-            first_channel + n_channels > p->tracks)
-            return gab::bad_arg("gab_conv_process_range: the range must lie inside the plan and start and end on multiples of 4 channels");
-        const size_t q0 = (size_t)first_channel / 2;
-        gab::ConvSplit sp{p->pmA2 + q0 * gab::kBinsA, p->pmF + q0 * gab::kBinsB,
-                          p->carry + q0 * gab::kCarrySlots * gab::kB, 0};
-        gab::conv_split_range_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, gab::as_stream(stream)>>>(
-            d_in + (size_t)first_channel * p->bufsize, d_out + first_channel,
-            p->hist + q0 * 2 * gab::kSlots * gab::kB, p->pmA + q0 * gab::kBinsA, sp, p->tw, p->tracks, p->head);
+        int rc = check_range(p, "gab_conv_process_range", first_channel, n_channels);
+        if (rc) return rc;
+        hipStream_t s = gab::as_stream(stream);
+        p->order_after_reset(s);
         p->fresh = false;
-        return gab::launch_status("conv_split_range_kernel");
+        return launch_range(p, d_in, d_out, first_channel, n_channels, p->head, s);
     });
 }
 
 // n_buffers consecutive buffers (input i = d_in[i % n_in]), each queued as n_ranges channel ranges
 // on their streams: the loop a native host would write around gab_conv_process_range /
-// gab_conv_advance, here so that an interpreted caller can keep several streams fed.
+// gab_conv_advance.  With more than one range every range gets its own host thread for the
+// duration of the call: a launch costs the host 3-4 us, so ONE thread feeding R streams cannot
+// queue faster than R x that per buffer, which is slower than the device runs them.
 int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in, float* d_out,
                            const int* first_channel, const int* n_channels, const gab_stream_t* streams,
                            int n_ranges, int n_buffers) {
-    if (!p || !d_in || !d_out || !first_channel || !n_channels || !streams)
-        return gab::bad_arg("gab_conv_stream_ranges: null argument");
-    if (n_in <= 0 || n_ranges <= 0 || n_buffers < 0) return gab::bad_arg("gab_conv_stream_ranges: counts must be positive");
-    for (int i = 0; i < n_buffers; ++i) {
+    return gab::guarded([&]() -> int {
+        if (!p || !d_in || !d_out || !first_channel || !n_channels || !streams)
+            return gab::bad_arg("gab_conv_stream_ranges: null argument");
+        if (n_in <= 0 || n_ranges <= 0 || n_buffers < 0) return gab::bad_arg("gab_conv_stream_ranges: counts must be positive");
+        if (!p->ir_set) return gab::bad_arg("gab_conv_stream_ranges: gab_conv_set_ir has not been called");
         for (int r = 0; r < n_ranges; ++r) {
-            int rc = gab_conv_process_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r], streams[r]);
+            int rc = check_range(p, "gab_conv_stream_ranges", first_channel[r], n_channels[r]);
             if (rc) return rc;
+            for (int q = 0; q < r; ++q)
+                if (first_channel[r] < first_channel[q] + n_channels[q] && first_channel[q] < first_channel[r] + n_channels[r])
+                    return gab::bad_arg("gab_conv_stream_ranges: ranges overlap");
         }
-        gab_conv_advance(p);
-    }
-    return GAB_OK;
+        for (int i = 0; i < n_in; ++i)
+            if (!d_in[i]) return gab::bad_arg("gab_conv_stream_ranges: null input buffer");
+        if (n_buffers == 0) return GAB_OK;
+        for (int r = 0; r < n_ranges; ++r) p->order_after_reset(gab::as_stream(streams[r]));
+        p->fresh = false;
+        const int head0 = p->head;
+        auto chain = [&](int r) -> int {
+            hipStream_t s = gab::as_stream(streams[r]);
+            for (int i = 0; i < n_buffers; ++i) {
+                int rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
+                                      (head0 + i) & (gab::kSlots - 1), s);
+                if (rc) return rc;
+            }
+            return GAB_OK;
+        };
+        static const bool one_thread = getenv("GAB_CONV_RANGE_THREADS") && atoi(getenv("GAB_CONV_RANGE_THREADS")) == 0;
+        int rc = GAB_OK;
+        if (n_ranges == 1) {
+            rc = chain(0);
+        } else if (one_thread) {
+            for (int i = 0; i < n_buffers && !rc; ++i)
+                for (int r = 0; r < n_ranges && !rc; ++r)
+                    rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
+                                      (head0 + i) & (gab::kSlots - 1), gab::as_stream(streams[r]));
+        } else {
+            std::vector<int> rcs(n_ranges, GAB_OK);
+            std::vector<std::string> errs(n_ranges);
+            std::vector<std::thread> workers;
+            for (int r = 1; r < n_ranges; ++r)
+                workers.emplace_back([&, r]() {
+                    if (hipSetDevice(p->device) != hipSuccess) { rcs[r] = GAB_ERR_RUNTIME; errs[r] = "hipSetDevice failed"; return; }
+                    rcs[r] = chain(r);
+                    if (rcs[r]) errs[r] = gab::last_error();      // the error text is thread-local
+                });
+            rcs[0] = chain(0);
+            for (auto& w : workers) w.join();
+            for (int r = 0; r < n_ranges; ++r)
+                if (rcs[r]) {
+                    rc = rcs[r];
+                    if (r) gab::set_last_error(errs[r]);
+                    break;
+                }
+        }
+        p->head = (head0 + n_buffers) & (gab::kSlots - 1);
+        return rc;
+    });
 }
 
 int gab_conv_advance(gab_conv_plan* p) {

@@ -1,0 +1,249 @@
+"""GPU parity at BASELINE.json's full sizes, against the CPU oracle (not against
+the HIP path itself):
+
+* conv1d_accel C3 (4096 taps x 1024 channels x 512) in STEADY STATE — ten
+  streamed buffers, every channel, vs the float64 direct form
+  (cuda/bench_conv1d_accel.cu:234-252 extended with carried history);
+* the split kernel's large-grid block -> (role, duo) mapping (grids that are a
+  multiple of 512 workgroups: T = 2048, 4096, 8192) on sampled channel duos;
+* fdtd3d C4 as BASELINE states it: 128^3 for 1000 leapfrog steps
+  (cuda/bench_fdtd3d.cu:14-139, 384-438), output AND pressure field bit-exact.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gab():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import gpuaudiobench_amd as g
+    return g
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+class ChunkedStreamOracle:
+    """orc_conv_accel_stream_f64 on a fixed set of channels, cut over host threads (the library
+    call releases the interpreter lock; channels are independent)."""
+
+    def __init__(self, orc, ir_rows, L, B):
+        self.orc, self.L, self.B = orc, L, B
+        n = ir_rows.shape[0]
+        k = min(_threads(), n)
+        edges = [n * i // k for i in range(k + 1)]
+        self.cuts = [(edges[i], edges[i + 1]) for i in range(k)]
+        self.irs = [np.ascontiguousarray(ir_rows[lo:hi]).ravel() for lo, hi in self.cuts]
+        self.hists = [np.zeros((hi - lo) * L, np.float32) for lo, hi in self.cuts]
+        self.pool = ThreadPoolExecutor(max_workers=k)
+
+    def step(self, x_rows):
+        """x_rows: (channels, B) -> (B, channels) sample-major float64-accumulated reference."""
+        def one(i):
+            lo, hi = self.cuts[i]
+            return self.orc.conv_accel_stream(np.ascontiguousarray(x_rows[lo:hi]).ravel(), self.irs[i],
+                                              self.hists[i], self.L, self.B, hi - lo, f64=True)
+        parts = list(self.pool.map(one, range(len(self.cuts))))
+        return np.concatenate([p.reshape(self.B, -1) for p in parts], axis=1)
+
+    def close(self):
+        self.pool.shutdown()
+
+
+def test_conv_accel_c3_steady_state_every_channel(gab, orc):
+    """BASELINE C3 at full size for 12 buffers: the carry ring, the far role and the parked shares
+    all contribute from buffer 2 on; every channel is compared with the float64 direct form."""
+    T, B, L, nbuf = 1024, 512, 4096, 12
+    ir = orc.conv_accel_ir(L, T)
+    ref = ChunkedStreamOracle(orc, ir.reshape(T, L), L, B)
+    plan = gab.ConvPlan(T, B, L)
+    assert plan.scheme == "split"
+    plan.set_ir(dev(ir))
+    max_abs, peak = 0.0, 0.0
+    for n in range(nbuf):
+        x = orc.noise(T * B, seed=4200 + n)
+        y = host(plan.process(dev(x), mode=gab.CONV_STREAMING)).reshape(B, T)
+        r = ref.step(x.reshape(T, B))
+        err = float(np.abs(y - r).max())
+        if n == 0 or n >= 8:                       # per-buffer gate once the window is full (and on the
+            assert err <= TOL * np.abs(r).max(), n  # reference-semantics first buffer)
+        max_abs, peak = max(max_abs, err), max(peak, float(np.abs(r).max()))
+    assert max_abs <= TOL * peak
+    assert peak > 1e-4                              # a developed steady-state signal, not the onset
+    ref.close()
+    plan.close()
+
+
+@pytest.mark.parametrize("T", [2048, 4096, 8192])
+def test_conv_accel_split_large_grid_role_mapping(gab, orc, T):
+    """Grids that are a multiple of 512 workgroups alternate the near/far roles in runs of 256
+    (k_conv_accel.hip conv_split_buffer): run >= 2 is only reached from T = 2048 on.  Sampled
+    channel duos — the first and last of every run of 256 workgroups plus random ones — are checked
+    against the oracle with the impulse responses generated at the GLOBAL channel index; the rest of
+    the channels must be finite and non-zero."""
+    B, L, nbuf = 512, 4096, 11
+    rng = np.random.default_rng(T)
+    duos = T // 4
+    picked = {0, duos - 1}
+    for run_start in range(0, duos, 256):
+        picked.update((run_start, min(run_start + 255, duos - 1)))
+    picked.update(int(v) for v in rng.integers(0, duos, 24))
+    chans = np.array(sorted(4 * d + j for d in picked for j in range(4)))
+    ir_full = orc.conv_accel_ir(L, T)
+    ir_rows = ir_full.reshape(T, L)[chans]
+    # the oracle's own global-index generator gives the same rows
+    one = chans[5]
+    assert np.array_equal(orc.conv_accel_ir(L, 1, track_offset=int(one), total_tracks=T), ir_full.reshape(T, L)[one])
+    ref = ChunkedStreamOracle(orc, ir_rows, L, B)
+    plan = gab.ConvPlan(T, B, L, scheme="split")
+    plan.set_ir(dev(ir_full))
+    del ir_full
+    max_abs, peak = 0.0, 0.0
+    for n in range(nbuf):
+        x = orc.noise(T * B, seed=77 + n)
+        y = host(plan.process(dev(x), mode=gab.CONV_STREAMING)).reshape(B, T)
+        r = ref.step(x.reshape(T, B)[chans])
+        err = float(np.abs(y[:, chans] - r).max())
+        if n == 0 or n >= 8:
+            assert err <= TOL * np.abs(r).max(), n
+        max_abs, peak = max(max_abs, err), max(peak, float(np.abs(r).max()))
+        assert np.isfinite(y).all()
+        if n >= 8:
+            assert (np.abs(y).max(axis=0) > 0).all()        # no channel left unwritten
+    assert max_abs <= TOL * peak
+    assert plan.scheme == "split"
+    ref.close()
+    plan.close()
+
+
+def test_conv_accel_large_grid_equals_shards(gab, orc):
+    """The whole T = 4096 output, bit for bit, against four 1024-channel plans fed the same
+    channels (a 512-workgroup grid, whose mapping the C3 test above pins to the oracle)."""
+    T, B, L, nbuf, S = 4096, 512, 4096, 10, 1024
+    ir = orc.conv_accel_ir(L, T).reshape(T, L)
+    big = gab.ConvPlan(T, B, L, scheme="split")
+    big.set_ir(dev(ir.ravel()))
+    shards = []
+    for k in range(T // S):
+        p = gab.ConvPlan(S, B, L, scheme="split")
+        p.set_ir(dev(ir[k * S:(k + 1) * S].ravel()))
+        shards.append(p)
+    for n in range(nbuf):
+        x = orc.noise(T * B, seed=900 + n).reshape(T, B)
+        y = host(big.process(dev(x.ravel()), mode=gab.CONV_STREAMING)).reshape(B, T)
+        for k, p in enumerate(shards):
+            ys = host(p.process(dev(x[k * S:(k + 1) * S].ravel()), mode=gab.CONV_STREAMING)).reshape(B, S)
+            assert np.array_equal(bits(y[:, k * S:(k + 1) * S]), bits(ys)), (n, k)
+    for p in shards + [big]:
+        p.close()
+
+
+def test_conv_accel_reset_then_ranges_without_host_sync(gab, orc):
+    """gab_conv_reset queues its memsets on the caller's stream; range launches on OTHER streams
+    must still see the cleared rings (the library orders them).  No host synchronisation between
+    the dirtying stream, the reset and the range launches."""
+    import torch
+    T, B, L = 1024, 512, 4096
+    ir = dev(orc.conv_accel_ir(L, T))
+    xs = [dev(orc.noise(T * B, seed=3100 + i)) for i in range(4)]
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    out = torch.empty(T * B, device="cuda")
+    for i in range(3):
+        ya = a.process(xs[i], mode=gab.CONV_STREAMING)
+    want = host(ya)
+    for trial in range(5):
+        for i in range(9):                              # dirty every ring slot
+            b.process(xs[(i + trial) % 4], mode=gab.CONV_STREAMING)
+        b.reset()
+        b.stream_ranges(xs, out, [(0, T // 2), (T // 2, T // 2)], [s1, s2], 3)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(host(out)), bits(want)), trial
+    a.close()
+    b.close()
+
+
+# ---------------------------------------------------------------------------
+def test_fdtd_c4_as_baseline_states_it(gab, orc):
+    """BASELINE C4: 128^3 grid, 1000 leapfrog steps (334 samples x 3 steps = 1002).  Output and
+    pressure field bit-exact against orc_fdtd(fused) — the restated kernels of
+    cuda/bench_fdtd3d.cu:14-139 in the order of runFDTD3DTimeStep (:384-438).  By then the front
+    has crossed the room several times: the receiver hears it and the planes next to the damped shell hold
+    developed values, which the LDS-halo kernels (the ones this grid takes) must reproduce on every face."""
+    import torch
+    n, T, B = 128, 8, 334
+    P = orc.fdtd_params(n)
+    G = gab.fdtd_default_params(n)
+    x = orc.Rand(1).bipolar(T * B)
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    plan = gab.FdtdPlan(G)
+    out = torch.zeros(T * B, device="cuda")
+    xd = dev(x)
+    for first, cnt in ((0, 100), (100, 134), (234, 100)):        # state carries across calls
+        plan.process(xd, out, T, B, first, cnt)
+        orc.fdtd(P, grids, x, ref, T, B, first, cnt, fused=True)
+    got = host(out)
+    assert np.array_equal(bits(got), bits(ref))
+    p_ref = grids[0].reshape(n, n, n)
+    p_got = host(plan.pressure())
+    assert np.array_equal(bits(p_got.ravel()), bits(p_ref.ravel()))
+    # the run is long enough to mean something
+    assert np.count_nonzero(ref.reshape(T, B)[0]) > 200          # the receiver hears the source
+    assert np.abs(ref).max() > 1e-6
+    # the outermost shell only ever sees p *= 0.8 from zero, so it is identically zero by
+    # construction (bench_fdtd3d.cu:86-97); the planes next to it carry the reflected field
+    assert not p_ref[0].any() and not p_ref[:, 0].any() and not p_ref[:, :, -1].any()
+    for face in (p_ref[1], p_ref[-2], p_ref[:, 1], p_ref[:, -2], p_ref[:, :, 1], p_ref[:, :, -2]):
+        inner = face[1:-1, 1:-1]
+        assert np.count_nonzero(np.abs(inner) > 1e-12) > 0.9 * inner.size     # developed values next to every face
+        assert np.abs(inner).max() > 1e-7
+    plan.close()
+
+
+def test_fdtd_wide_slab_cut_developed_field(gab, orc):
+    """One >= 68-wide slab cut (rows that take the LDS-halo step kernel) run long enough for the
+    front to cross the cut planes many times: 96^3, three uneven slabs, 120 samples = 360 steps,
+    bit-exact against the oracle's single grid."""
+    import torch
+    from gpuaudiobench_amd import fdtd_slabs
+    n, T, B = 96, 4, 120
+    P = orc.fdtd_params(n)
+    G = gab.fdtd_default_params(n)
+    x = orc.Rand(1).bipolar(T * B)
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+    slabs = [fdtd_slabs.FdtdSlab(G, a, b) for a, b in [(0, 30), (30, 71), (71, 96)]]
+    out = torch.zeros(T * B, device="cuda")
+    fdtd_slabs.process_local(slabs, dev(x), out, T, B)
+    field = torch.cat([s.pressure() for s in slabs]).cpu().numpy().ravel()
+    assert np.array_equal(bits(host(out)), bits(ref))
+    assert np.array_equal(bits(field), bits(grids[0]))
+    assert np.count_nonzero(ref.reshape(T, B)[0]) > 60
+    for s in slabs:
+        s.close()
