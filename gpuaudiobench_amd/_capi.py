@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgab_hip.so")
+# GAB_LIB_PATH: a diagnostic build of the same library (see build.py, GAB_BUILD_TAG)
+LIB_PATH = os.environ.get("GAB_LIB_PATH") or os.path.join(_HERE, "libgab_hip.so")
 
 GAB_OK = 0
 GAB_ERR_INVALID_ARG = -1

@@ -13,9 +13,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "libgab_hip.so")
-DRIVER = os.path.join(HERE, "gpubench")
+# GAB_BUILD_TAG=<tag>: a diagnostic build beside the product one (libgab_hip_<tag>.so, own object
+# directory); load it with GAB_LIB_PATH.  The product library is always libgab_hip.so.
+_TAG = os.environ.get("GAB_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "_build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "libgab_hip%s.so" % ("_" + _TAG if _TAG else ""))
+DRIVER = os.path.join(HERE, "gpubench" + ("_" + _TAG if _TAG else ""))
 
 ARCH = "gfx950"
 # -ffp-contract=off: a*b+c is never fused behind our back; kernels that want an
@@ -87,7 +90,7 @@ def build(force=False, driver=True, verbose=False):
         if (force or not os.path.exists(DRIVER)
                 or os.path.getmtime(DRIVER) < max(os.path.getmtime(LIB), os.path.getmtime(main_src), hdr_m)):
             cmd = [_hipcc()] + FLAGS + ["-x", "hip", main_src, "-o", DRIVER,
-                                        "-L" + HERE, "-lgab_hip", "-Wl,-rpath,$ORIGIN"]
+                                        "-L" + HERE, "-l:" + os.path.basename(LIB), "-Wl,-rpath,$ORIGIN"]
             subprocess.check_call(cmd)
             if verbose:
                 print("linked", DRIVER)

@@ -514,6 +514,16 @@ struct WaveFFT1024 {
         t.w1 = tw[(lane & 3) * (kTwiddleN / 64)];
         powers_of<16>(tw[lane * (kTwiddleN / 1024)], t.w2);
     }
+    // The same in two steps, for callers that want the two table reads at the head of their
+    // request stream and the power expansion later: raw leaves W1024^lane in w2[0].
+    __device__ static __forceinline__ void load_twiddles_raw(Twiddles& t, const cf* __restrict__ tw, int lane) {
+        t.w1 = tw[(lane & 3) * (kTwiddleN / 64)];
+        t.w2[0] = tw[lane * (kTwiddleN / 1024)];
+    }
+    __device__ static __forceinline__ void expand_twiddles(Twiddles& t) {
+        const cf b = t.w2[0];
+        powers_of<16>(b, t.w2);
+    }
 
     __device__ static __forceinline__ void run(cf (&v)[16], cf* __restrict__ img, const Twiddles& t,
                                                int lane_in) {

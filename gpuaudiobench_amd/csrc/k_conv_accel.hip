@@ -170,6 +170,26 @@ __device__ unsigned long long g_conv_stamps[8 * 4096];
 #endif
 #define GAB_STAMP(i) GAB_STAMP_T(i, 0)
 
+#ifdef GAB_ABLATE
+// split kernel (debug bit 64): [launch parity][block][8] of s_memrealtime; slot 6 = HW_ID, 7 = XCC_ID.
+// Bit 128 additionally drains the wave's loads (s_waitcnt vmcnt(0)) before slot 1, so that slot 1
+// reads "all of this wave's data has arrived" (that changes the timing it measures).
+__device__ unsigned long long g_split_stamps[2 * 8 * 8192];
+#define GAB_SSTAMP(i)                                                                          \
+    do {                                                                                       \
+        if (sp.debug & 64) {                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            if (threadIdx.x == 0)                                                              \
+                g_split_stamps[((head & 1) * 8192 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    } while (0)
+#define GAB_SDRAIN() do { if (sp.debug & 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#else
+#define GAB_SSTAMP(i) do {} while (0)
+#define GAB_SDRAIN() do {} while (0)
+#endif
+
 // (Tried and measured slower, so not kept: running partition B first in half of
 // the workgroups to de-phase the two workgroups that share a CU, 14.8 vs 14.0 us;
 // a 512-thread radix-8 form of this kernel (8 values per thread, 4 passes), 16.6 us:
@@ -400,7 +420,7 @@ __device__ __forceinline__ void conv_split_buffer(
     int slot;                                                         // index within the role
     if ((gridDim.x & 511) == 0) {
         const int run = blockIdx.x >> 8;
-        far = (run & 1) != 0;
+        far = ((run & 1) != 0) != ((sp.debug & 256) != 0);           // debug 256: far workgroups first
         slot = (run >> 1) * 256 + (blockIdx.x & 255);
     } else {
         far = (int)blockIdx.x >= duos;
@@ -408,8 +428,16 @@ __device__ __forceinline__ void conv_split_buffer(
     }
     const int d = xcd_contiguous(slot, duos);
 
+    GAB_SSTAMP(0);
+#ifdef GAB_ABLATE
+    if ((sp.debug & 64) && threadIdx.x == 0) {
+        g_split_stamps[((head & 1) * 8192 + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+        g_split_stamps[((head & 1) * 8192 + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+    }
+#endif
     if (far) {
         if (sp.debug & 4) return;
+        if (sp.debug & 512) __builtin_amdgcn_s_setprio(2);
         // ---- F of one pair: window = the seven newest blocks of the ring + the new block
         const int q = 2 * d + (head & 1);
         const int ta = 2 * q, tb = ta + 1;
@@ -438,21 +466,29 @@ __device__ __forceinline__ void conv_split_buffer(
         __builtin_amdgcn_sched_barrier(0);
         typename FB::Twiddles twb;
         FB::expand_twiddles(twb_base, twb);
+        GAB_SDRAIN();
+        GAB_SSTAMP(1);
         FB::run(zb, X, Y, twb, tid);
+        GAB_SSTAMP(2);
         cf zpb[16];
         partner_exchange<kNB, 16, true>(zb, zpb, X, tid);
         spectral_product<kNB, 16>(zb, zpb, cb, tid);
+        GAB_SSTAMP(3);
         FBi::template run<typename FB::Twiddles, 4>(zb, Y, X, twb, tid);     // only [12..15]
+        GAB_SSTAMP(4);
         cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;            // block k+1
         cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;            // block k+2
+        if (sp.debug & 16) { keep_alive(zb[12]); keep_alive(zb[13]); keep_alive(zb[14]); keep_alive(zb[15]); return; }
         c1[tid] = zb[12];
         c1[tid + kThreads] = zb[13];
         c2[tid] = zb[14];
         c2[tid + kThreads] = zb[15];
+        GAB_SSTAMP(5);
         return;
     }
 
     if (sp.debug & 1) return;
+    if (sp.debug & 1024) __builtin_amdgcn_s_setprio(2);
     // ---- near: wave w holds one 1024-point transform: pair (w >> 1) of the duo, window w & 1
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -466,6 +502,9 @@ __device__ __forceinline__ void conv_split_buffer(
     using WF = fft::WaveFFT1024<false>;
     using WFi = fft::WaveFFT1024<true>;
 
+    WF::Twiddles t;
+    WF::load_twiddles_raw(t, tw, lane);          // requested first: a wave's loads return in order, and
+                                                 // the forward transform needs these before the spectra
     cf z[16];
     if (!second) {
         const float* xa = in + (size_t)ta * kB;
@@ -483,13 +522,16 @@ __device__ __forceinline__ void conv_split_buffer(
     __builtin_amdgcn_sched_barrier(0);
     float4 c[16];
     load_spectra<kNA, 16>(c, (second ? sp.pmA2 : pmA) + (size_t)q * kBinsA, lane);
-    WF::Twiddles t;
-    WF::load_twiddles(t, tw, lane);
-    if (!second) {                                                    // the new block enters the ring
+    __builtin_amdgcn_sched_barrier(0);
+    WF::expand_twiddles(t);
+    if (!second && !(sp.debug & 8)) {                                 // the new block enters the ring
 #pragma unroll
         for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = z[8 + j];
     }
+    GAB_SDRAIN();
+    GAB_SSTAMP(1);
     WF::run(z, img, t, lane);
+    GAB_SSTAMP(2);
     const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
     {
         cf zp[16];
@@ -506,22 +548,68 @@ __device__ __forceinline__ void conv_split_buffer(
         for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
     }
     __syncthreads();
+    GAB_SSTAMP(3);
+    cf y[8];
+    const bool pieces8 = (sp.debug & 2048) != 0;      // A/B: one float2 per pair and sample, no swap
+    if (pieces8 && second) return;
+    if (!second) {
+        {
+            const cf* const other = img + kWaveImg;                   // the A2 transform of the same pair
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = fft::cadd(z[r], other[rb + 68 * r]);
+        }
+        const cf* const cy = sp.carry + ((size_t)q * kCarrySlots + (head & (kCarrySlots - 1))) * kB;
+        cf park[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) park[j] = cy[lane + 64 * j];
+        WFi::run(z, img, t, lane);
+        GAB_SSTAMP(4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+        if (pieces8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<float2*>(out + (size_t)T * (lane + 64 * j) + ta) = make_float2(y[j].x, y[j].y);
+            return;
+        }
+        // The two pairs of a duo are four neighbouring channels: 16 bytes per sample.  The waves
+        // swap halves through LDS so that each stores float4 pieces — half as many partial-line
+        // writes into L2 as with one float2 per pair (the output scatter is 8 KiB-strided).
+        // Wave 0 (pair 0) keeps samples lane + 64 j, j < 4, wave 2 (pair 1) keeps j >= 4.
+        if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[4 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
+        }
+    }
+    __syncthreads();
     if (second) return;
+    if (sp.debug & 32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keep_alive(y[j]);
+        return;
+    }
     {
-        const cf* const other = img + kWaveImg;                       // the A2 transform of the same pair
+        float* const o0 = out + 4 * (size_t)d;
+        if (w == 0) {
+            const cf* const other = lds + 2 * kWaveImg;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = fft::cadd(z[r], other[rb + 68 * r]);
+            for (int j = 0; j < 4; ++j) {
+                const cf theirs = other[lane + 64 * j];
+                *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * j)) = make_float4(y[j].x, y[j].y, theirs.x, theirs.y);
+            }
+        } else {
+            const cf* const other = lds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cf theirs = other[lane + 64 * j];
+                *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * (4 + j))) = make_float4(theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+            }
+        }
     }
-    const cf* const cy = sp.carry + ((size_t)q * kCarrySlots + (head & (kCarrySlots - 1))) * kB;
-    cf park[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) park[j] = cy[lane + 64 * j];
-    WFi::run(z, img, t, lane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float* o = out + (size_t)T * (lane + 64 * j) + ta;
-        *reinterpret_cast<float2*>(o) = make_float2(z[8 + j].x + park[j].x, z[8 + j].y + park[j].y);
-    }
+    GAB_SSTAMP(5);
 }
 
 __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(
@@ -578,6 +666,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
     for (int nb = 0; nb < n_buffers; ++nb)
         conv_one_buffer<true, true, 0>(in + nb * step, out + nb * step, hist, pmA, pmB, tw, T,
                                        (head + nb) & (kSlots - 1), lds);
+}
+
+// Occupies one wave for about `ticks` of the 100 MHz real-time counter: offsets the phase of a chain
+// of launches against the chains on other streams (gab_conv_stream_ranges).
+__global__ void conv_phase_delay_kernel(unsigned ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 // IR bank -> (P, M) spectra of a near (512 taps from offA) and a far (taps from offB) partition.
@@ -1056,8 +1151,11 @@ int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in,
         for (int r = 0; r < n_ranges; ++r) p->order_after_reset(gab::as_stream(streams[r]));
         p->fresh = false;
         const int head0 = p->head;
+        static const int phase_ticks = getenv("GAB_CONV_PHASE_TICKS") ? atoi(getenv("GAB_CONV_PHASE_TICKS")) : 0;
         auto chain = [&](int r) -> int {
             hipStream_t s = gab::as_stream(streams[r]);
+            if (r > 0 && phase_ticks > 0)
+                gab::conv_phase_delay_kernel<<<1, 64, 0, s>>>((unsigned)(phase_ticks * r));
             for (int i = 0; i < n_buffers; ++i) {
                 int rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
                                       (head0 + i) & (gab::kSlots - 1), s);
@@ -1164,6 +1262,10 @@ int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* histor
 int gab_debug_conv_stamps(unsigned long long* h_out, int n) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_conv_stamps), sizeof(unsigned long long) * n);
+}
+int gab_debug_split_stamps(unsigned long long* h_out, int n) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_split_stamps), sizeof(unsigned long long) * n);
 }
 #endif
 

@@ -1,0 +1,4 @@
+# GAB_CONV_SPLIT_DEBUG bits: 1 near off, 4 far off, 8 no ring write, 16 no carry write, 32 no output write,
+# 256 far workgroups first, 512 far at raised priority, 1024 near at raised priority, 2048 float2 output pieces
+for d in 0 2048 4 2052 60; do echo -n "debug=$d  "; GAB_CONV_SPLIT_DEBUG=$d tools/ubench/bin/two_chains --chains 1 --buffers 4000; done
+for d in 0 2048; do echo -n "2 chains debug=$d  "; GAB_CONV_SPLIT_DEBUG=$d tools/ubench/bin/two_chains --chains 2 --buffers 4000; done
