@@ -4,24 +4,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one audio buffer (512 new samples for every one of a rank's 1024
-channels) pushed through the fused overlap-save kernel with carried history.
-Inputs are resident in HBM before the timed region.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank owns a 1024-channel shard
-of an N*1024-channel job: rank 0 generates the whole impulse-response bank, it
-is broadcast over RCCL/xGMI once, each rank transforms its slice; there is no
-per-buffer collective (channels are independent), so scaling is weak.
+A "step" is one pass of the hot path over the resident batch of synthetic input:
+BUFFERS_PER_STEP = 32 consecutive audio buffers (512 new samples for every one of a
+rank's 1024 channels), each pushed through the fused overlap-save kernel with
+carried history — one launch (or one set of channel-range launches) per buffer, each
+depending on the one before.  Inputs are resident in HBM before the timed region.
+
+With N > 1 every rank owns a 1024-channel shard of an N*1024-channel job: rank 0
+generates the whole impulse-response bank, it is broadcast over RCCL/xGMI once,
+each rank transforms its slice; there is no per-buffer collective (channels are
+independent), so scaling is weak.  A plain `python bench.py --gpus N` starts the N
+ranks itself (torch.distributed.run) before touching any GPU and relays rank 0's line.
 
 One JSON line on rank 0:
-  value      = 1024-channel buffers per second, whole job (N * K / max-rank time)
-  roofline   = algorithmic bytes per launch / average kernel duration (HIP events
-               on the launch stream), against the 8 TB/s HBM peak
-  cpu_baseline = the CPU oracle (reference golden extended with history), one
-               core, timed on a bounded sample of the same workload (N=1 only)
+  value        = 1024-channel buffers per second, whole job (N * 32 K / max-rank time)
+  roofline     = algorithmic bytes per buffer / device period per buffer (HIP events
+                 on the launch streams over the timed region), against 8 TB/s HBM
+  cpu_baseline = the CPU oracle (the reference golden extended with history), timed on a
+                 bounded sample of the same workload on this box's cores (N = 1 only)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,8 +38,11 @@ TRACKS_PER_GPU = 1024
 BUFSIZE = 512
 TAPS = 4096
 FS = 48000
-N_INPUT_BUFFERS = 16            # distinct input buffers cycled through (32 MiB of HBM)
+BUFFERS_PER_STEP = 32           # the resident input batch: distinct buffers cycled through (64 MiB)
+CLOCK_WARM_BUFFERS = 3000       # untimed, besides --warmup: clocks and caches at their running state
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+DEFAULT_STREAMS = 2             # channel ranges per buffer, each on its own stream (1 = one launch per buffer)
+TRAFFIC_SOURCE = "profiles/pmc_traffic.json"
 
 
 def cpu_threads():
@@ -58,32 +66,101 @@ def algorithmic_bytes(tracks, bufsize, taps):
     return 4 * tracks * (2 * bufsize + 2 * taps)
 
 
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` as a plain command: start N fresh rank processes (one per GPU) with
+    torch.distributed.run, relay rank 0's JSON line, return the launcher's exit code.  Runs before
+    this process has imported torch or touched a GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
+        return 1
+    return proc.returncode
+
+
+def dry_run(args, rank, world):
+    """GAB_BENCH_DRYRUN=1: the launcher, rendezvous, bank broadcast and timing collectives on CPU
+    tensors over gloo, with NO device work — what the CPU test suite can run of the N > 1 path.
+    The line says so and carries no measurement."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from gpuaudiobench_amd import sharding
+    T, L = int(os.environ.get("GAB_BENCH_DRYRUN_TRACKS", "8")), 64
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t0 = time.perf_counter()
+    ir = sharding.broadcast_ir_bank(L, T * world, rank, world, torch.device("cpu"), dist if world > 1 else None)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    lo, hi = sharding.shard_range(rank, world, T * world)
+    ok = bool(np.array_equal(ir.numpy().ravel(), __import__("gpuaudiobench_amd").harness.conv_accel_ir(L, hi - lo, lo, T * world)))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    elapsed = time.perf_counter() - t0 + 1e-9
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed, 1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t2 = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MIN)
+        ok = bool(t2.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "audio_buffers_per_sec", "value": None, "unit": "buffers/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "DRY RUN (GAB_BENCH_DRYRUN=1): rendezvous, bank broadcast and collectives "
+                                  "on CPU over gloo; no device work, no measurement",
+                          "config": {"workload": "dry run", "ir_broadcast_ms": bcast_ms,
+                                     "ir_slices_match_global_bank": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--roundtrip-iters", type=int, default=300)
-    ap.add_argument("--paced-iters", type=int, default=150)
-    # these launches run at PCIe speed; they use the kernel's host-io name, so a rocprofv3 --stats
-    # average of the timed kernel is not skewed by them
-    ap.add_argument("--zero-copy-iters", type=int, default=300)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps of %d buffers each" % BUFFERS_PER_STEP)
+    ap.add_argument("--warmup", type=int, default=15, help="untimed steps (besides the fixed clock warm-up)")
+    ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
+                    help="channel ranges per buffer, one HIP stream and host thread each (1 = one launch per buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="only the timed region (profiling runs)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if os.environ.get("GAB_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
     # GAB_BENCH_REHEARSE=1: every rank on device 0 with gloo, to walk the N>1 code path on a one-GPU
     # box (ranks then share the device, so the rate means nothing; the line says so in `data`)
     rehearse = os.environ.get("GAB_BENCH_REHEARSE") == "1"
@@ -102,6 +179,7 @@ def main():
 
     T, B, L = TRACKS_PER_GPU, BUFSIZE, TAPS
     T_total = T * world
+    NB = BUFFERS_PER_STEP
 
     # ---- impulse-response bank: generated once, broadcast over RCCL -------------
     from gpuaudiobench_amd import sharding
@@ -114,169 +192,69 @@ def main():
     plan = gab.ConvPlan(T, B, L)
     plan.set_ir(ir_dev)
     spectra_bytes, history_bytes = plan.state_bytes()
+    R = args.streams if plan.scheme == "split" else 1
+    if R < 1 or T % (4 * R):
+        raise SystemExit("--streams must cut %d channels into ranges that are multiples of 4" % T)
 
     # ---- synthetic input: the reference's noise generator, this rank's channels --
     inputs = [torch.from_numpy(sharding.shard_noise(T_total, B, rank, world, seed=42 + i)).to(dev)
-              for i in range(N_INPUT_BUFFERS)]
+              for i in range(NB)]
     out = torch.empty(T * B, dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream()
+    main_stream = torch.cuda.current_stream()
+    if R == 1:
+        streams = [main_stream]
+        step_args = [plan.prepare(x, out, gab.CONV_STREAMING) for x in inputs]
+        launch_one = plan.launch
 
-    # one gab_conv_process call per buffer; the ctypes arguments are built once per input buffer so
-    # that the timed loop stays device-bound (a launch costs the host ~4 us this way, ~7.5 us through
-    # ConvPlan.process, against ~9 us of device time)
-    step_args = [plan.prepare(x, out, gab.CONV_STREAMING) for x in inputs]
-    launch_one = plan.launch
+        def run_buffers(n):            # one gab_conv_process call per buffer, arguments prepared once
+            for i in range(n):
+                launch_one(step_args[i % NB])
+    else:
+        streams = [torch.cuda.Stream() for _ in range(R)]
+        ranges = [(r * (T // R), T // R) for r in range(R)]
 
-    def step(i):
-        launch_one(step_args[i % N_INPUT_BUFFERS])
+        def run_buffers(n):            # the library's launch loop: one host thread and one stream per range
+            plan.stream_ranges(inputs, out, ranges, streams, n)
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(k):
+        run_buffers(k * NB)
+
+    run_buffers(CLOCK_WARM_BUFFERS)
+    run_steps(args.warmup)
 
     # ---- timed region -------------------------------------------------------------
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
-        step(i)
-    ev1.record(stream)
+    for s, (a, _) in zip(streams, ev):
+        a.record(s)
+    run_steps(args.steps)
+    for s, (_, b) in zip(streams, ev):
+        b.record(s)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1)                 # device view of the same K launches
+    n_buffers = args.steps * NB
+    region_ms = max(a.elapsed_time(b) for a, b in ev)      # device view of the same launches
+    period_us = region_ms * 1e3 / n_buffers
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # ---- per-launch kernel duration: one event pair per launch (outside `value`) ---
-    n_pairs = min(args.steps, 400)
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-             for _ in range(n_pairs)]
-    for i, (a, b) in enumerate(pairs):
-        a.record(stream)
-        step(i)
-        b.record(stream)
-    torch.cuda.synchronize()
-    kernel_us = float(np.mean([a.elapsed_time(b) for a, b in pairs]) * 1e3)
-    period_us = region_ms * 1e3 / args.steps
-
-    # ---- batch mode (not `value`): 16 buffers per launch, for callers that have the input ahead
-    # of time; same results, no kernel boundary between buffers ------------------------------
-    nb = 16
-    xb = torch.cat([inputs[i % N_INPUT_BUFFERS] for i in range(nb)])
-    yb = torch.empty_like(xb)
-    for _ in range(20):
-        plan.process_batch(xb, nb, out=yb)
-    eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    eb0.record(stream)
-    nrep = max(1, min(args.steps, 3200) // nb)
-    for _ in range(nrep):
-        plan.process_batch(xb, nb, out=yb)
-    eb1.record(stream)
-    torch.cuda.synchronize()
-    batch_us = eb0.elapsed_time(eb1) * 1e3 / (nrep * nb)
-    del xb, yb
-    plan.reset()          # a batch call moves the history ring with the classic cut; back to the plan's own
-
-    # ---- pipelined mode (not `value`): the stateless kernel (history = the caller's last eight
-    # input buffers), consecutive buffers alternating between two streams, so the device overlaps
-    # the end of one launch with the start of the next.  One launch per buffer, same bits. ------
-    side = [torch.cuda.Stream(), torch.cuda.Stream()]
-    outs2 = [torch.empty(T * B, dtype=torch.float32, device=dev) for _ in side]
-    prepared = []
-    for i in range(N_INPUT_BUFFERS * len(side)):           # (input index, stream) repeats with this period
-        prev = [inputs[(i - k) % N_INPUT_BUFFERS] for k in range(1, 9)]
-        j = i % len(side)
-        prepared.append(plan.prepare_windowed(inputs[i % N_INPUT_BUFFERS], prev, outs2[j], side[j]))
-    launch = plan.launch_prepared
-    n_pipe = min(args.steps, 4000)
-    for i in range(200):
-        launch(prepared[i % len(prepared)])
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(n_pipe):
-        launch(prepared[i % len(prepared)])
-    torch.cuda.synchronize()
-    pipe_us = (time.perf_counter() - t1) * 1e6 / n_pipe
-
-    # ---- channel ranges on two streams (not `value`): the same buffers, each launched as two
-    # halves of the channels on two streams.  Channels are independent, so every stream is its own
-    # chain of dependent launches and the chains overlap each other's kernel boundaries.  Same bits.
-    two_us = None
-    if plan.scheme == "split" and T % 8 == 0:
-        plan.reset()
-        halves = [(0, T // 2), (T // 2, T // 2)]
-        plan.stream_ranges(inputs, out, halves, side, 200)
-        torch.cuda.synchronize()
-        n_two = min(args.steps, 3000)
-        t1 = time.perf_counter()
-        plan.stream_ranges(inputs, out, halves, side, n_two)     # the launch loop runs in the library
-        torch.cuda.synchronize()
-        two_us = (time.perf_counter() - t1) * 1e6 / n_two
-        plan.reset()
-
-    # ---- p50 round trip: pinned host -> HBM -> kernel -> HBM -> pinned host ----------
-    h_in = torch.from_numpy(gab.harness.noise(T * B, seed=7)).pin_memory()
-    h_out = torch.empty(T * B, dtype=torch.float32).pin_memory()
-    d_in = torch.empty(T * B, dtype=torch.float32, device=dev)
-    rt = []
-    for i in range(args.roundtrip_iters + 20):
-        t1 = time.perf_counter()
-        d_in.copy_(h_in, non_blocking=True)
-        plan.process(d_in, out=out, mode=gab.CONV_STREAMING)
-        h_out.copy_(out, non_blocking=True)
-        stream.synchronize()
-        if i >= 20:
-            rt.append((time.perf_counter() - t1) * 1e6)
-    rt = np.array(rt)
-
-    # ---- zero-copy round trip: the kernel reads the pinned input and writes the pinned output
-    # itself (no copy commands); same buffer, same history sequence ----------------------------
-    zc = None
-    if args.zero_copy_iters > 0:
-        h_out_zc = torch.empty(T * B, dtype=torch.float32).pin_memory()
-        zc = []
-        for i in range(args.zero_copy_iters + 20):
-            t1 = time.perf_counter()
-            plan.process(h_in, out=h_out_zc, mode=gab.CONV_STREAMING)
-            stream.synchronize()
-            if i >= 20:
-                zc.append((time.perf_counter() - t1) * 1e6)
-        zc = np.array(zc)
-        plan.reset()      # host-io launches use the classic cut; back to the plan's own
-
-    # ---- the same round trip under DAW pacing: one buffer per 512/48000 s slot, device idle in
-    # between (the Metal port's DAWSimulator) --------------------------------------
-    paced = []
-    daw = gab.harness.DawSim(buffer_seconds=float(B) / FS, mode="spin")
-    for i in range(args.paced_iters + 5):
-        daw.wait()
-        t1 = time.perf_counter()
-        d_in.copy_(h_in, non_blocking=True)
-        plan.process(d_in, out=out, mode=gab.CONV_STREAMING)
-        h_out.copy_(out, non_blocking=True)
-        stream.synchronize()
-        if i >= 5:
-            paced.append((time.perf_counter() - t1) * 1e6)
-    paced = np.array(paced) if paced else np.array([float("nan")])
-    paced_waits, paced_missed = daw.stats()
-    daw.close()
+    wall_us = elapsed * 1e6 / n_buffers
 
     alg = algorithmic_bytes(T, B, L)
-    # achieved is priced on the launch period of the timed region (kernel time plus
-    # the inter-launch gap): that is what back-to-back buffers actually cost.
-    achieved = alg / (period_us * 1e-6) / 1e9
+    side = {}
+    if not args.no_side_legs:
+        side = side_legs(gab, plan, inputs, out, main_stream, R, dev, T, B, L, np, torch)
+
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_file = os.path.join(ROOT, TRAFFIC_SOURCE)
     if os.path.exists(pmc_file):
         try:
             traffic = json.load(open(pmc_file)).get(
@@ -284,9 +262,10 @@ def main():
         except Exception:
             traffic = None
 
+    achieved = alg / (period_us * 1e-6) / 1e9
     result = {
         "metric": "audio_buffers_per_sec",
-        "value": world * args.steps / elapsed,
+        "value": world * n_buffers / elapsed,
         "unit": "buffers/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -299,102 +278,198 @@ def main():
         "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: all ranks share device 0 over gloo",
         "config": {
             "workload": "bench_conv1d_accel streaming overlap-save: %d-tap IR x %d channels x "
-                        "%d-sample buffers @ %d Hz per GPU (BASELINE configs[2]%s)"
+                        "%d-sample buffers @ %d Hz per GPU (BASELINE configs[2]%s); one step = %d consecutive buffers"
                         % (L, T, B, FS, "; configs[4]-style channel sharding, %d channels total" % T_total
-                           if world > 1 else ""),
+                           if world > 1 else "", NB),
             "taps": L, "channels_per_gpu": T, "channels_total": T_total, "buffer_size": B, "fs": FS,
+            "buffers_per_step": NB, "us_per_buffer": wall_us,
             "mode": "streaming", "tap_cut": plan.scheme,
-            "realtime_factor": (world * args.steps / elapsed) * B / FS,
-            "p50_round_trip_us": float(np.percentile(rt, 50)),
-            "p95_round_trip_us": float(np.percentile(rt, 95)),
-            "p50_round_trip_zero_copy_us": float(np.percentile(zc, 50)) if zc is not None else None,
-            "p95_round_trip_zero_copy_us": float(np.percentile(zc, 95)) if zc is not None else None,
-            "paced_10p667ms": {"p50_round_trip_us": float(np.percentile(paced, 50)),
-                               "p95_round_trip_us": float(np.percentile(paced, 95)),
-                               "max_round_trip_us": float(paced.max()),
-                               "slots": int(paced_waits), "missed_slots": int(paced_missed)},
-            "batch_mode_16_buffers_per_launch": {"us_per_buffer": batch_us, "buffers_per_sec": 1e6 / batch_us,
-                                                 "alg_GBps": algorithmic_bytes(T, B, L) / batch_us / 1e3},
-            "pipelined_two_streams_stateless_kernel": {"us_per_buffer": pipe_us, "buffers_per_sec": 1e6 / pipe_us,
-                                                       "alg_GBps": algorithmic_bytes(T, B, L) / pipe_us / 1e3},
-            "channel_halves_on_two_streams": None if two_us is None else {
-                "us_per_buffer": two_us, "buffers_per_sec": 1e6 / two_us,
-                "alg_GBps": algorithmic_bytes(T, B, L) / two_us / 1e3},
+            "launches_per_buffer": R,
+            "launch_path": ("gab_conv_process, one launch per buffer" if R == 1 else
+                            "gab_conv_stream_ranges: %d channel ranges per buffer, one stream and host thread each" % R),
+            "clock_warm_buffers": CLOCK_WARM_BUFFERS,
+            "realtime_factor": (world * n_buffers / elapsed) * B / FS,
             "ir_broadcast_ms": bcast_ms,
             "state_bytes": {"spectra": spectra_bytes, "history": history_bytes},
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "conv_split_kernel" if plan.scheme == "split" else "conv_overlap_save_kernel<true,true>",
+            "kernel": ("conv_split_kernel" if R == 1 else "conv_split_range_kernel x%d per buffer" % R)
+                      if plan.scheme == "split" else "conv_overlap_save_kernel<true,true>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "frac_wall": alg / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg,
-            "launch_period_us": period_us,
-            "kernel_us_event_pairs": kernel_us,
+            "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of an earlier run, not measured in this one)"
+                              if traffic is not None else None,
+            "algorithmic_bytes_per_buffer": alg,
+            "device_period_us_per_buffer": period_us,
+            "wall_period_us_per_buffer": wall_us,
         },
     }
+    result["config"].update(side)
 
-    # ---- CPU baseline: the oracle, one core, bounded sample (rank 0, N = 1) ------------
+    # ---- CPU baseline: the oracle on this box's cores, bounded sample (rank 0, N = 1) ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        import oracle                     # checker / baseline only — never the product path
-        from concurrent.futures import ThreadPoolExecutor
-        ir_host = ir_dev.cpu().numpy().reshape(T, L)
-        xs = [inputs[i].cpu().numpy().reshape(T, B) for i in range(N_INPUT_BUFFERS)]
-        budget = args.cpu_baseline_seconds / 2.0
-
-        # (i) the reference's golden as it runs it: scalar loops, one thread
-        hist = np.zeros(T * L, np.float32)
-        t1 = time.perf_counter()
-        oracle.conv_accel_stream(xs[0].ravel(), ir_host.ravel(), hist, L, B, T)
-        first = time.perf_counter() - t1
-        n_one = max(1, min(20, int(budget / first) - 1))
-        t1 = time.perf_counter()
-        for i in range(n_one):
-            oracle.conv_accel_stream(xs[(i + 1) % N_INPUT_BUFFERS].ravel(), ir_host.ravel(), hist, L, B, T)
-        dt_one = time.perf_counter() - t1
-
-        # (ii) the same loops with the channels cut over every core this process may use (the
-        # library call releases the interpreter lock; channels are independent)
-        cores = max(1, min(cpu_threads(), T))
-        cuts = [sharding.shard_range(k, cores, T) for k in range(cores)]
-        hists = [np.zeros((hi - lo) * L, np.float32) for lo, hi in cuts]
-        irs = [np.ascontiguousarray(ir_host[lo:hi]).ravel() for lo, hi in cuts]
-        xcut = [[np.ascontiguousarray(x[lo:hi]).ravel() for lo, hi in cuts] for x in xs]
-
-        def one(k, i):
-            lo, hi = cuts[k]
-            oracle.conv_accel_stream(xcut[i % N_INPUT_BUFFERS][k], irs[k], hists[k], L, B, hi - lo)
-
-        with ThreadPoolExecutor(max_workers=cores) as pool:
-            list(pool.map(lambda k: one(k, 0), range(cores)))            # warm
-            n_all = max(2, min(200, int(budget * cores / first * 0.8)))
-            t1 = time.perf_counter()
-            for i in range(n_all):
-                list(pool.map(lambda k, i=i: one(k, i + 1), range(cores)))
-            dt_all = time.perf_counter() - t1
-        result["cpu_baseline"] = {
-            "value": n_all / dt_all,
-            "unit": "buffers/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": "%d buffers of the full %d-channel x %d-tap workload, direct-form fp32 "
-                      "(oracle/gab_oracle.c orc_conv_accel_stream), channels cut over %d threads, %.1f s; "
-                      "single thread (as the reference runs its golden): %d buffers in %.1f s"
-                      % (n_all, T, L, cores, dt_all, n_one, dt_one),
-            "single_thread_value": n_one / dt_one,
-        }
+        result["cpu_baseline"] = cpu_baseline(args, ir_dev, inputs, T, B, L, np)
     elif rank == 0:
         result["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     plan.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def side_legs(gab, plan, inputs, out, stream, R, dev, T, B, L, np, torch):
+    """Rates that are NOT `value`, each with a fixed iteration count (independent of --steps)."""
+    NB = len(inputs)
+    alg = algorithmic_bytes(T, B, L)
+    res = {}
+
+    # ---- the same buffers as ONE launch per buffer on one stream, HIP events around 4000 launches
+    plan.reset()
+    step_args = [plan.prepare(x, out, gab.CONV_STREAMING) for x in inputs]
+    for i in range(500):
+        plan.launch(step_args[i % NB])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for i in range(4000):
+        plan.launch(step_args[i % NB])
+    e1.record(stream)
+    torch.cuda.synchronize()
+    one_us = e0.elapsed_time(e1) * 1e3 / 4000
+    res["one_launch_per_buffer_single_stream"] = {
+        "kernel": "conv_split_kernel" if plan.scheme == "split" else "conv_overlap_save_kernel<true,true>",
+        "us_per_buffer": one_us, "buffers_per_sec": 1e6 / one_us, "alg_GBps": alg / one_us / 1e3,
+        "frac": alg / one_us / 1e3 / HBM_PEAK_GBS, "launches": 4000}
+
+    # ---- batch mode: 16 buffers per launch, for callers that hold the input ahead of time
+    nb = 16
+    xb = torch.cat([inputs[i % NB] for i in range(nb)])
+    yb = torch.empty_like(xb)
+    for _ in range(20):
+        plan.process_batch(xb, nb, out=yb)
+    eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eb0.record(stream)
+    for _ in range(150):
+        plan.process_batch(xb, nb, out=yb)
+    eb1.record(stream)
+    torch.cuda.synchronize()
+    batch_us = eb0.elapsed_time(eb1) * 1e3 / (150 * nb)
+    res["batch_mode_16_buffers_per_launch"] = {"us_per_buffer": batch_us, "buffers_per_sec": 1e6 / batch_us,
+                                               "alg_GBps": alg / batch_us / 1e3, "launches": 150}
+    del xb, yb
+    plan.reset()          # a batch call moves the history ring with the classic cut; back to the plan's own
+
+    # ---- p50 round trip: pinned host -> HBM -> kernel -> HBM -> pinned host, one buffer in flight
+    h_in = torch.from_numpy(gab.harness.noise(T * B, seed=7)).pin_memory()
+    h_out = torch.empty(T * B, dtype=torch.float32).pin_memory()
+    d_in = torch.empty(T * B, dtype=torch.float32, device=dev)
+    rt = []
+    for i in range(320):
+        t1 = time.perf_counter()
+        d_in.copy_(h_in, non_blocking=True)
+        plan.process(d_in, out=out, mode=gab.CONV_STREAMING)
+        h_out.copy_(out, non_blocking=True)
+        stream.synchronize()
+        if i >= 20:
+            rt.append((time.perf_counter() - t1) * 1e6)
+    rt = np.array(rt)
+    res["p50_round_trip_us"] = float(np.percentile(rt, 50))
+    res["p95_round_trip_us"] = float(np.percentile(rt, 95))
+
+    # ---- zero-copy round trip: the kernel reads the pinned input and writes the pinned output itself
+    h_out_zc = torch.empty(T * B, dtype=torch.float32).pin_memory()
+    zc = []
+    for i in range(220):
+        t1 = time.perf_counter()
+        plan.process(h_in, out=h_out_zc, mode=gab.CONV_STREAMING)
+        stream.synchronize()
+        if i >= 20:
+            zc.append((time.perf_counter() - t1) * 1e6)
+    zc = np.array(zc)
+    plan.reset()          # host-io launches use the classic cut; back to the plan's own
+    res["p50_round_trip_zero_copy_us"] = float(np.percentile(zc, 50))
+    res["p95_round_trip_zero_copy_us"] = float(np.percentile(zc, 95))
+
+    # ---- the same round trip under DAW pacing: one buffer per 512/48000 s slot, device idle between
+    paced = []
+    daw = gab.harness.DawSim(buffer_seconds=float(B) / FS, mode="spin")
+    for i in range(105):
+        daw.wait()
+        t1 = time.perf_counter()
+        d_in.copy_(h_in, non_blocking=True)
+        plan.process(d_in, out=out, mode=gab.CONV_STREAMING)
+        h_out.copy_(out, non_blocking=True)
+        stream.synchronize()
+        if i >= 5:
+            paced.append((time.perf_counter() - t1) * 1e6)
+    paced = np.array(paced)
+    waits, missed = daw.stats()
+    daw.close()
+    res["paced_10p667ms"] = {"p50_round_trip_us": float(np.percentile(paced, 50)),
+                             "p95_round_trip_us": float(np.percentile(paced, 95)),
+                             "max_round_trip_us": float(paced.max()),
+                             "slots": int(waits), "missed_slots": int(missed)}
+    return res
+
+
+def cpu_baseline(args, ir_dev, inputs, T, B, L, np):
+    import oracle                     # checker / baseline only — never the product path
+    from concurrent.futures import ThreadPoolExecutor
+    from gpuaudiobench_amd import sharding
+    NB = len(inputs)
+    ir_host = ir_dev.cpu().numpy().reshape(T, L)
+    xs = [inputs[i].cpu().numpy().reshape(T, B) for i in range(NB)]
+    budget = args.cpu_baseline_seconds / 2.0
+
+    # (i) the reference's golden as it runs it: scalar loops, one thread
+    hist = np.zeros(T * L, np.float32)
+    t1 = time.perf_counter()
+    oracle.conv_accel_stream(xs[0].ravel(), ir_host.ravel(), hist, L, B, T)
+    first = time.perf_counter() - t1
+    n_one = max(1, min(20, int(budget / first) - 1))
+    t1 = time.perf_counter()
+    for i in range(n_one):
+        oracle.conv_accel_stream(xs[(i + 1) % NB].ravel(), ir_host.ravel(), hist, L, B, T)
+    dt_one = time.perf_counter() - t1
+
+    # (ii) the same loops with the channels cut over every core this process may use (the
+    # library call releases the interpreter lock; channels are independent)
+    cores = max(1, min(cpu_threads(), T))
+    cuts = [sharding.shard_range(k, cores, T) for k in range(cores)]
+    hists = [np.zeros((hi - lo) * L, np.float32) for lo, hi in cuts]
+    irs = [np.ascontiguousarray(ir_host[lo:hi]).ravel() for lo, hi in cuts]
+    xcut = [[np.ascontiguousarray(x[lo:hi]).ravel() for lo, hi in cuts] for x in xs]
+
+    def one(k, i):
+        lo, hi = cuts[k]
+        oracle.conv_accel_stream(xcut[i % NB][k], irs[k], hists[k], L, B, hi - lo)
+
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        list(pool.map(lambda k: one(k, 0), range(cores)))            # warm
+        n_all = max(2, min(200, int(budget * cores / first * 0.8)))
+        t1 = time.perf_counter()
+        for i in range(n_all):
+            list(pool.map(lambda k, i=i: one(k, i + 1), range(cores)))
+        dt_all = time.perf_counter() - t1
+    return {
+        "value": n_all / dt_all,
+        "unit": "buffers/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d buffers of the full %d-channel x %d-tap workload, direct-form fp32 "
+                  "(oracle/gab_oracle.c orc_conv_accel_stream), channels cut over %d threads, %.1f s; "
+                  "single thread (as the reference runs its golden): %d buffers in %.1f s"
+                  % (n_all, T, L, cores, dt_all, n_one, dt_one),
+        "single_thread_value": n_one / dt_one,
+    }
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -423,8 +423,8 @@ __device__ __forceinline__ void conv_split_buffer(
         far = ((run & 1) != 0) != ((sp.debug & 256) != 0);           // debug 256: far workgroups first
         slot = (run >> 1) * 256 + (blockIdx.x & 255);
     } else {
-        far = (int)blockIdx.x >= duos;
-        slot = far ? blockIdx.x - duos : blockIdx.x;
+        far = ((int)blockIdx.x >= duos) != ((sp.debug & 256) != 0);
+        slot = (int)blockIdx.x >= duos ? blockIdx.x - duos : blockIdx.x;
     }
     const int d = xcd_contiguous(slot, duos);
 
@@ -1097,10 +1097,10 @@ int check_range(const gab_conv_plan* p, const char* who, int first_channel, int 
 
 // the launch itself; `head` is the ring slot of this buffer
 int launch_range(gab_conv_plan* p, const float* d_in, float* d_out, int first_channel, int n_channels,
-                 int head, hipStream_t s) {
+                 int head, hipStream_t s, int flags = 0) {
     const size_t q0 = (size_t)first_channel / 2;
     gab::ConvSplit sp{p->pmA2 + q0 * gab::kBinsA, p->pmF + q0 * gab::kBinsB,
-                      p->carry + q0 * gab::kCarrySlots * gab::kB, 0};
+                      p->carry + q0 * gab::kCarrySlots * gab::kB, flags};
     gab::conv_split_range_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, s>>>(
         d_in + (size_t)first_channel * p->bufsize, d_out + first_channel,
         p->hist + q0 * 2 * gab::kSlots * gab::kB, p->pmA + q0 * gab::kBinsA, sp, p->tw, p->tracks, head);
@@ -1152,13 +1152,15 @@ int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in,
         p->fresh = false;
         const int head0 = p->head;
         static const int phase_ticks = getenv("GAB_CONV_PHASE_TICKS") ? atoi(getenv("GAB_CONV_PHASE_TICKS")) : 0;
+        static const int swap_odd = getenv("GAB_CONV_RANGE_SWAP") ? atoi(getenv("GAB_CONV_RANGE_SWAP")) : 0;
         auto chain = [&](int r) -> int {
             hipStream_t s = gab::as_stream(streams[r]);
+            const int flags = (swap_odd && (r & 1)) ? 256 : 0;
             if (r > 0 && phase_ticks > 0)
                 gab::conv_phase_delay_kernel<<<1, 64, 0, s>>>((unsigned)(phase_ticks * r));
             for (int i = 0; i < n_buffers; ++i) {
                 int rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
-                                      (head0 + i) & (gab::kSlots - 1), s);
+                                      (head0 + i) & (gab::kSlots - 1), s, flags);
                 if (rc) return rc;
             }
             return GAB_OK;
