@@ -777,6 +777,131 @@ __global__ __launch_bounds__(kThreads) void fft_r2c_1024_kernel(
     }
 }
 
+// ---- uniform partitions: every other power-of-two buffer size, impulse responses up to 16384 taps ----
+// The reference sizes ONE transform as nextpow2(L + B - 1) for any (ir_length, buffer_size)
+// (cuda/bench_conv1d_accel.cu:49-53).  Here the taps are cut into J partitions, each convolved with
+// its own 4096-sample window of the history by the same 4096-point transform:
+//   partition 0      taps [0, B)                          window ends at the newest sample
+//   partition p >= 1 taps [B + (p-1) S, B + p S), S = 4096 - B   window ends B + (p-1) S samples earlier
+// (S is a multiple of B, so windows start on block boundaries of the stream).  The J spectral
+// products are summed before ONE inverse transform, of which the last B outputs are the block.
+// Partition 0 is kept to the B taps that can reach a first buffer: every other window then holds
+// nothing but history, so after a reset their products are exact zeros and the first buffer is the
+// reference's golden to rounding of the small leading taps (the large centre taps of a long
+// response would otherwise bury it under their round-off).
+// State: a time-domain ring of ring_len samples per channel pair; a sample's ring index is its
+// absolute index in the stream modulo ring_len, so no block arithmetic is needed anywhere.
+// Bytes per buffer and pair: J x (32 KiB window + 32.8 KB spectra) + 8 B x B in + out + ring.
+struct ConvUniform {
+    const float4* pm;      // [J][pairs][kBinsB]
+    cf* ring;              // [pairs][ring_len]
+    int J, S, ring_mask;
+    unsigned pos;          // absolute index (mod ring_len) of the new block's first sample
+};
+
+template <bool STREAM>
+__global__ __launch_bounds__(kThreads, 2) void conv_uniform_kernel(
+    const float* __restrict__ in, float* __restrict__ out, ConvUniform u, const cf* __restrict__ tw,
+    int T, int B) {
+    __shared__ cf lds[2 * kLdsHalf];
+    cf* const X = lds;
+    cf* const Y = lds + kLdsHalf;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const int ta = 2 * q, tb = ta + 1;
+    const bool hasb = tb < T;
+    const int pairs = gridDim.x;
+    using FB = fft::BlockFFT<kNB, 16, false>;
+    using FBi = fft::BlockFFT<kNB, 16, true>;
+    typename FB::Bases twb;
+    FB::load_twiddles(twb, tw, tid);
+    cf* const ring = u.ring + (size_t)q * (u.ring_mask + 1);
+    const float* const xa = in + (size_t)ta * B;
+    const float* const xb = in + (size_t)tb * B;
+    const int newest = kNB - B;                    // window positions >= newest are the new block (partition 0)
+
+    cf acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = mk(0.0f, 0.0f);
+    const int J = STREAM ? u.J : 1;
+    for (int j = 0; j < J; ++j) {
+        const unsigned back = j == 0 ? 0u : (unsigned)(B + (j - 1) * u.S);      // how far this window ends before the newest sample
+        cf z[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = tid + kThreads * r;
+            if (j == 0 && n >= newest) {
+                const int s = n - newest;
+                z[r] = mk(xa[s], hasb ? xb[s] : 0.0f);
+            } else if (STREAM) {
+                z[r] = ring[(u.pos + (unsigned)(n - newest) - back) & (unsigned)u.ring_mask];
+            } else {
+                z[r] = mk(0.0f, 0.0f);
+            }
+        }
+        float4 c[16];
+        load_spectra<kNB, 16>(c, u.pm + ((size_t)j * pairs + q) * kBinsB, tid);
+        FB::run(z, X, Y, twb, tid);                          // last reads Y
+        cf zp[16];
+        partner_exchange<kNB, 16, true>(z, zp, X, tid);      // writes X, barrier, reads X
+        spectral_product<kNB, 16>(z, zp, c, tid);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fft::cadd(acc[r], z[r]);
+        __syncthreads();                                      // X's readers are done before the next forward writes it
+    }
+    FBi::run(acc, X, Y, twb, tid);
+    if (STREAM) {
+        // the new block enters the ring (its slot holds the oldest samples, which no window reaches)
+        for (int s = tid; s < B; s += kThreads)
+            ring[(u.pos + (unsigned)s) & (unsigned)u.ring_mask] = mk(xa[s], hasb ? xb[s] : 0.0f);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = tid + kThreads * r;
+        if (n >= newest) {
+            float* o = out + (size_t)T * (n - newest) + ta;
+            o[0] = acc[r].x;
+            if (hasb) o[1] = acc[r].y;
+        }
+    }
+}
+
+// (P, M) spectra of taps [off, off + count) of every pair, zero-padded to 4096 (1/N folded in).
+__global__ __launch_bounds__(kThreads) void conv_ir_spectra_uniform_kernel(
+    const float* __restrict__ ir, float4* __restrict__ pm, const cf* __restrict__ tw, int T, int L,
+    int off, int count) {
+    __shared__ cf lds[2 * kLdsHalf];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const int ta = 2 * q, tb = ta + 1;
+    const bool hasb = tb < T;
+    const float* ia = ir + (size_t)ta * L;
+    const float* ib = ir + (size_t)tb * L;
+    cf z[16], zp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = tid + r * kThreads;
+        const int j = off + m;
+        z[r] = (m < count && j < L) ? mk(ia[j], hasb ? ib[j] : 0.0f) : mk(0.0f, 0.0f);
+    }
+    fft::BlockFFT<kNB, 16, false>::Twiddles t;
+    fft::BlockFFT<kNB, 16, false>::load_twiddles(t, tw, tid);
+    fft::BlockFFT<kNB, 16, false>::run(z, lds, lds + kLdsHalf, t, tid);
+    partner_exchange<kNB, 16>(z, zp, lds, tid);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = tid + r * kThreads;
+        if (k <= kNB / 2) {
+            cf sm = fft::cadd(z[r], zp[r]), df = fft::csub(z[r], zp[r]);
+            cf Ha = mk(0.5f * sm.x, 0.5f * sm.y);
+            cf Hb = mk(0.5f * df.y, -0.5f * df.x);
+            const float sc = 0.5f / kNB;
+            pm[(size_t)q * kBinsB + k] = make_float4(sc * (Ha.x + Hb.x), sc * (Ha.y + Hb.y),
+                                                     sc * (Ha.x - Hb.x), sc * (Ha.y - Hb.y));
+        }
+    }
+}
+
 // Direct-form fallback for shapes the fused path does not cover (bufsize != 512
 // or ir_len > 4096): y[T*s+t] = sum_{k<L} x_hist[s-k] h[k], history ring of
 // `hlen` samples per track (hlen >= L-1, multiple of bufsize).  One thread per
@@ -844,6 +969,12 @@ struct gab_conv_plan {
     size_t carry_bytes = 0;
     bool split_live = false;
     bool fresh = true;        // nothing has run since the last reset
+    // uniform partitions (conv_uniform_kernel): other power-of-two buffer sizes / longer responses
+    bool uniform = false;
+    int uJ = 0, uS = 0, ring_len = 0;
+    unsigned upos = 0;
+    float4* pmU = nullptr;
+    gab::fft::cf* ring = nullptr;
     // Ordering between gab_conv_reset (memsets on the caller's stream) and launches on OTHER streams
     // (channel ranges): the reset waits for every stream that launched since the previous reset, and
     // a stream's first launch after a reset waits for the reset's event.
@@ -880,8 +1011,23 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
         GAB_HIP_CHECK(hipEventCreateWithFlags(&p->reset_ev, hipEventDisableTiming));
         p->fused = (bufsize == gab::kB && ir_len <= gab::kNB);
         p->tail = ir_len > gab::kB;
+        const bool pow2 = (bufsize & (bufsize - 1)) == 0;
+        p->uniform = !p->fused && pow2 && bufsize >= 32 && bufsize <= 2048 && ir_len <= 16384;
         try {
-            if (p->fused) {
+            if (p->uniform) {
+                p->tw = gab::fft::device_twiddles();
+                p->uS = gab::kNB - bufsize;
+                p->uJ = 1 + (ir_len > bufsize ? (ir_len - bufsize + p->uS - 1) / p->uS : 0);
+                // oldest sample any window reaches, plus the slot the new block is written to
+                int need = gab::kNB + bufsize + (p->uJ > 1 ? bufsize + (p->uJ - 2) * p->uS : 0);
+                p->ring_len = gab::kNB;
+                while (p->ring_len < need) p->ring_len *= 2;
+                p->spectra_bytes = sizeof(float4) * (size_t)p->uJ * p->pairs * gab::kBinsB;
+                p->history_bytes = sizeof(gab::fft::cf) * (size_t)p->pairs * p->ring_len;
+                GAB_HIP_CHECK(hipMalloc(&p->pmU, p->spectra_bytes));
+                GAB_HIP_CHECK(hipMalloc(&p->ring, p->history_bytes));
+                GAB_HIP_CHECK(hipMemset(p->ring, 0, p->history_bytes));
+            } else if (p->fused) {
                 p->tw = gab::fft::device_twiddles();
                 size_t a = sizeof(float4) * (size_t)p->pairs * gab::kBinsA;
                 size_t b = p->tail ? sizeof(float4) * (size_t)p->pairs * gab::kBinsB : 0;
@@ -932,6 +1078,8 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->pmA2) (void)hipFree(p->pmA2);
     if (p->pmF) (void)hipFree(p->pmF);
     if (p->carry) (void)hipFree(p->carry);
+    if (p->pmU) (void)hipFree(p->pmU);
+    if (p->ring) (void)hipFree(p->ring);
     if (p->reset_ev) (void)hipEventDestroy(p->reset_ev);
     delete p;
     return GAB_OK;
@@ -941,7 +1089,14 @@ int gab_conv_set_ir(gab_conv_plan* p, const float* d_ir, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p || !d_ir) return gab::bad_arg("gab_conv_set_ir: null argument");
         hipStream_t s = gab::as_stream(stream);
-        if (p->fused) {
+        if (p->uniform) {
+            for (int j = 0; j < p->uJ; ++j)
+                gab::conv_ir_spectra_uniform_kernel<<<p->pairs, gab::kThreads, 0, s>>>(
+                    d_ir, p->pmU + (size_t)j * p->pairs * gab::kBinsB, p->tw, p->tracks, p->ir_len,
+                    j == 0 ? 0 : p->bufsize + (j - 1) * p->uS, j == 0 ? p->bufsize : p->uS);
+            int rc = gab::launch_status("conv_ir_spectra_uniform_kernel");
+            if (rc) return rc;
+        } else if (p->fused) {
             // pmB is null when ir_len <= 512: the kernel then skips partition B
             gab::conv_ir_spectra_kernel<<<p->pairs, gab::kThreads, 0, s>>>(
                 d_ir, p->pmA, p->pmB, p->tw, p->tracks, p->ir_len, 0, gab::kB);
@@ -995,8 +1150,10 @@ int gab_conv_reset(gab_conv_plan* p, gab_stream_t stream) {
             p->used_streams.clear();
             p->ordered_streams.clear();
         }
-        GAB_HIP_CHECK(hipMemsetAsync(p->hist, 0, p->history_bytes, s));
+        if (p->uniform) GAB_HIP_CHECK(hipMemsetAsync(p->ring, 0, p->history_bytes, s));
+        else GAB_HIP_CHECK(hipMemsetAsync(p->hist, 0, p->history_bytes, s));
         p->head = 0;
+        p->upos = 0;
         if (p->carry) GAB_HIP_CHECK(hipMemsetAsync(p->carry, 0, p->carry_bytes, s));
         {
             std::lock_guard<std::mutex> lock(p->order_mu);
@@ -1020,6 +1177,20 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
         hipStream_t s = gab::as_stream(stream);
         const bool streaming = mode != GAB_CONV_STATELESS;
         if (streaming) p->order_after_reset(s);
+        if (p->uniform) {
+            if (mode == GAB_CONV_STREAMING_HOST_IO) mode = GAB_CONV_STREAMING;      // same kernel, host pointers
+            gab::ConvUniform u{p->pmU, p->ring, p->uJ, p->uS, p->ring_len - 1, p->upos};
+            if (streaming) {
+                gab::conv_uniform_kernel<true><<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
+                    d_in, d_out, u, p->tw, p->tracks, p->bufsize);
+                p->upos = (p->upos + (unsigned)p->bufsize) & (unsigned)(p->ring_len - 1);
+                p->fresh = false;
+            } else {
+                gab::conv_uniform_kernel<false><<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
+                    d_in, d_out, u, p->tw, p->tracks, p->bufsize);
+            }
+            return gab::launch_status("conv_uniform_kernel");
+        }
         if (p->fused) {
             dim3 grid(p->pairs), block(gab::kThreads);
 #define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head

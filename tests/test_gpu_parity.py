@@ -259,8 +259,18 @@ def test_conv_accel_linearity_and_shard_equality(gab, orc):
     shard.close()
 
 
-@pytest.mark.parametrize("B,L,T", [(256, 512, 8), (128, 1000, 3), (1024, 6000, 2)])
-def test_conv_accel_other_shapes_fallback(gab, orc, B, L, T):
+@pytest.mark.parametrize("B,L,T,nbuf", [
+    (256, 512, 8, 6), (128, 1000, 3, 12), (1024, 6000, 2, 9),      # the reference takes any (ir_length, buffer_size)
+    (512, 8192, 4, 20), (512, 16384, 2, 36),                        # longer than one 4096-point window: 3 and 5 partitions
+    (256, 4096, 64, 20), (64, 4096, 5, 70), (32, 700, 3, 40), (2048, 3000, 2, 4),
+    (1024, 16384, 1, 20), (128, 16384, 2, 140),
+])
+def test_conv_accel_uniform_partitions(gab, orc, B, L, T, nbuf):
+    """Every other power-of-two buffer size and impulse responses up to 16384 taps run fused as well
+    (conv_uniform_kernel: partitions of 4096 - B taps, one 4096-point transform each, one inverse):
+    reference semantics on a stateless call, and a stream long enough for the oldest partition's
+    window to fill, against the float64 direct form (cuda/bench_conv1d_accel.cu:234-252 extended
+    with carried history); reset forgets."""
     ir = orc.conv_accel_ir(L, T)
     hist = np.zeros(T * L, np.float32)
     plan = gab.ConvPlan(T, B, L)
@@ -269,7 +279,36 @@ def test_conv_accel_other_shapes_fallback(gab, orc, B, L, T):
     assert peak_err(host(plan.process(dev(x), mode=gab.CONV_STATELESS)),
                     orc.conv_accel(x, ir, L, B, T)) <= TOL
     max_abs, stream_peak = 0.0, 0.0
-    for n in range(3):
+    full = (L + B - 1) // B                                   # buffers until every tap sees real history
+    for n in range(nbuf):
+        x = orc.noise(T * B, seed=7 + n)
+        ref = orc.conv_accel_stream(x, ir, hist, L, B, T, f64=True)
+        y = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
+        if n == 0 or n >= full:
+            assert peak_err(y, ref) <= TOL, (n, peak_err(y, ref))
+        max_abs = max(max_abs, np.abs(y - ref).max())
+        stream_peak = max(stream_peak, np.abs(ref).max())
+    assert nbuf > full or L > 8 * B
+    assert max_abs / stream_peak <= TOL
+    plan.reset()
+    x = orc.noise(T * B, seed=99)
+    y = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
+    assert peak_err(y, orc.conv_accel(x, ir, L, B, T)) <= TOL
+    plan.close()
+
+
+@pytest.mark.parametrize("B,L,T", [(300, 700, 3), (48, 100, 2), (4096, 512, 1)])
+def test_conv_accel_direct_form_last_resort(gab, orc, B, L, T):
+    """Buffer sizes that are not a power of two (or beyond 2048) keep the direct-form kernel."""
+    ir = orc.conv_accel_ir(L, T)
+    hist = np.zeros(T * L, np.float32)
+    plan = gab.ConvPlan(T, B, L)
+    plan.set_ir(dev(ir))
+    x = orc.noise(T * B)
+    assert peak_err(host(plan.process(dev(x), mode=gab.CONV_STATELESS)),
+                    orc.conv_accel(x, ir, L, B, T)) <= TOL
+    max_abs, stream_peak = 0.0, 0.0
+    for n in range(4):
         x = orc.noise(T * B, seed=7 + n)
         ref = orc.conv_accel_stream(x, ir, hist, L, B, T, f64=True)
         y = host(plan.process(dev(x), mode=gab.CONV_STREAMING))
