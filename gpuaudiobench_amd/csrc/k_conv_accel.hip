@@ -195,19 +195,12 @@ __device__ unsigned long long g_split_stamps[2 * 8 * 8192];
 // a 512-thread radix-8 form of this kernel (8 values per thread, 4 passes), 16.6 us:
 // the transforms are bound by LDS write bandwidth and VALU throughput, not by the
 // per-thread instruction chain, and radix-8 needs a third exchange.)
-// The 8 blocks before the current one, as the caller's own input buffers (track-major T x 512
-// floats each): blk[0] = block n-1 ... blk[7] = block n-8.  With these the kernel keeps no state.
-struct ConvWindow {
-    const float* blk[kSlots];
-};
-
-// One buffer of one channel pair; the body of the kernels below.  WINDOWED: the history comes
-// from `win` instead of the plan's ring, and nothing is written but the output.
-template <bool STREAM, bool TAIL, int ABL, bool WINDOWED = false>
+// One buffer of one channel pair; the body of the kernels below.
+template <bool STREAM, bool TAIL, int ABL>
 __device__ __forceinline__ void conv_one_buffer(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
-    const cf* __restrict__ tw, int T, int head, cf* __restrict__ lds, const ConvWindow* win = nullptr) {
+    const cf* __restrict__ tw, int T, int head, cf* __restrict__ lds) {
     cf* const lds0 = lds;
     cf* const lds1 = lds + kLdsHalf;
 
@@ -239,15 +232,7 @@ __device__ __forceinline__ void conv_one_buffer(
         za[2] = mk(xa[tid], hasb ? xb[tid] : 0.0f);
         za[3] = mk(xa[tid + kThreads], hasb ? xb[tid + kThreads] : 0.0f);
     }
-    // element (block j back, sample s) of this pair, from the caller's buffers
-    auto from_window = [&](int back, int s) {
-        const float* b = win->blk[back - 1];
-        return mk(b[(size_t)ta * kB + s], hasb ? b[(size_t)tb * kB + s] : 0.0f);
-    };
-    if constexpr (WINDOWED) {
-        za[0] = from_window(1, tid);
-        za[1] = from_window(1, tid + kThreads);
-    } else if constexpr (STREAM) {
+    if constexpr (STREAM) {
         const int off = ((head + kSlots - 1) & (kSlots - 1)) * kB + tid;
         za[0] = hp[off];
         za[1] = hp[off + kThreads];
@@ -265,15 +250,14 @@ __device__ __forceinline__ void conv_one_buffer(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 14; ++r) {
-            if constexpr (WINDOWED) zb[r] = from_window(kSlots - (r >> 1), (r & 1) * kThreads + tid);   // oldest first
-            else zb[r] = hp[((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid];
+            zb[r] = hp[((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid];      // oldest first
         }
         zb[14] = za[0];
         zb[15] = za[1];
     }
     __builtin_amdgcn_sched_barrier(0);
     FA::expand_twiddles(twa_base, twa);      // while the first loads are in flight
-    if constexpr (STREAM && !WINDOWED) {
+    if constexpr (STREAM) {
         // overwrite the oldest block (already requested into zb[0..1]) with the new one
         hp[head * kB + tid] = za[2];
         hp[head * kB + kThreads + tid] = za[3];
@@ -639,17 +623,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_host_io_kernel(
     const cf* __restrict__ tw, int T, int head) {
     __shared__ cf lds[2 * kLdsHalf];
     conv_one_buffer<true, TAIL, 0>(in, out, hist, pmA, pmB, tw, T, head, lds);
-}
-
-// Stateless form: the history is the caller's last eight input buffers.  Launches no longer
-// depend on each other, so a caller may put consecutive buffers on different streams and let the
-// device overlap the end of one with the start of the next.
-__global__ __launch_bounds__(kThreads, 2) void conv_windowed_kernel(
-    const float* __restrict__ in, float* __restrict__ out, ConvWindow win,
-    const float4* __restrict__ pmA, const float4* __restrict__ pmB,
-    const cf* __restrict__ tw, int T) {
-    __shared__ cf lds[2 * kLdsHalf];
-    conv_one_buffer<true, true, 0, true>(in, out, nullptr, pmA, pmB, tw, T, 0, lds, &win);
 }
 
 // The launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup walks them
@@ -1131,7 +1104,9 @@ int gab_conv_set_scheme(gab_conv_plan* p, int scheme) {
 
 int gab_conv_get_scheme(const gab_conv_plan* p, int* scheme) {
     if (!p || !scheme) return gab::bad_arg("gab_conv_get_scheme: null pointer");
-    *scheme = p->split ? GAB_CONV_SCHEME_SPLIT : GAB_CONV_SCHEME_CLASSIC;
+    // what the NEXT streaming launch will use: a split plan that a batch, host-io or set_ir call has
+    // moved on without the carry ring runs classic launches until its next reset
+    *scheme = (p->split && p->split_live) ? GAB_CONV_SCHEME_SPLIT : GAB_CONV_SCHEME_CLASSIC;
     return GAB_OK;
 }
 
@@ -1402,28 +1377,10 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
     });
 }
 
-int gab_conv_process_windowed(gab_conv_plan* p, const float* d_in, const float* const* d_previous,
-                              float* d_out, gab_stream_t stream) {
-    return gab::guarded([&]() -> int {
-        if (!p || !d_in || !d_previous || !d_out) return gab::bad_arg("gab_conv_process_windowed: null argument");
-        if (!p->ir_set) return gab::bad_arg("gab_conv_process_windowed: gab_conv_set_ir has not been called");
-        if (!(p->fused && p->tail))
-            return gab::bad_arg("gab_conv_process_windowed: needs bufsize 512 and 512 < ir_len <= 4096");
-        gab::ConvWindow w;
-        for (int k = 0; k < gab::kSlots; ++k) {
-            if (!d_previous[k]) return gab::bad_arg("gab_conv_process_windowed: null history buffer");
-            w.blk[k] = d_previous[k];
-        }
-        gab::conv_windowed_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, gab::as_stream(stream)>>>(
-            d_in, d_out, w, p->pmA, p->pmB, p->tw, p->tracks);
-        return gab::launch_status("conv_windowed_kernel");
-    });
-}
-
 int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* history) {
     if (!p) return gab::bad_arg("gab_conv_state_bytes: null plan");
     // everything resident for the plan: a plan that can use the split cut holds both sets of spectra
-    // (classic for batch / windowed / host-io launches) and the carry ring beside the history ring
+    // (classic for batch / host-io launches) and the carry ring beside the history ring
     const size_t bank = p->pmF ? sizeof(float4) * (size_t)p->pairs * (gab::kBinsA + gab::kBinsB) : 0;
     if (spectra) *spectra = p->spectra_bytes + bank;
     if (history) *history = p->history_bytes + p->carry_bytes;

@@ -181,17 +181,6 @@ class ConvPlan:
         check(lib.gab_conv_process_batch(self._h, _dev(x), _dev(out), n_buffers, _stream()))
         return out
 
-    def process_windowed(self, x, previous, out=None, stream=None):
-        """Stateless: `previous` = the last eight input buffers, newest first (device tensors, same
-        layout as x; zeros for "before the stream").  `stream`: a torch.cuda.Stream, default current."""
-        assert len(previous) == 8
-        if out is None:
-            out = torch.empty(self.tracks * self.bufsize, dtype=torch.float32, device=x.device)
-        ptrs = (C.c_void_p * 8)(*[_dev(t).value for t in previous])
-        st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
-        check(lib.gab_conv_process_windowed(self._h, _dev(x), ptrs, _dev(out), st))
-        return out
-
     def process_range(self, x, out, first_channel, n_channels, stream=None):
         """gab_conv_process_range: one buffer, channels [first, first + n) only; x / out are the
         whole buffers.  Call advance() once per buffer after all its ranges are queued."""
@@ -228,17 +217,6 @@ class ConvPlan:
     @staticmethod
     def launch(args):
         check(lib.gab_conv_process(*args))
-
-    def prepare_windowed(self, x, previous, out, stream):
-        """The ctypes arguments of process_windowed, built once: a loop that cycles through a fixed
-        set of buffers replays them with `launch_prepared` at ~4 us of host time per call."""
-        assert len(previous) == 8
-        ptrs = (C.c_void_p * 8)(*[_dev(t).value for t in previous])
-        return (self._h, _dev(x), ptrs, _dev(out), C.c_void_p(stream.cuda_stream))
-
-    @staticmethod
-    def launch_prepared(args):
-        check(lib.gab_conv_process_windowed(*args))
 
     def state_bytes(self):
         a, b = C.c_size_t(0), C.c_size_t(0)

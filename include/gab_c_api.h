@@ -145,9 +145,11 @@ typedef struct gab_conv_plan gab_conv_plan;
  *   SPLIT    taps [0,512) + [512,1024) + [1024,4096): the far partition runs for a pair every
  *            other buffer, one buffer ahead, on its own workgroups (conv_split_kernel).  Same
  *            convolution, different rounding: results agree to ~1e-7 of the peak, not bit for bit.
- * gab_conv_process_batch, gab_conv_process_windowed and host-io launches always use the CLASSIC
- * cut; after a batch or host-io call a SPLIT plan continues with CLASSIC launches until the next
- * gab_conv_reset.                                                                                */
+ * gab_conv_process_batch and host-io launches always use the CLASSIC cut; after a batch or host-io
+ * call a SPLIT plan continues with CLASSIC launches until the next gab_conv_reset, and
+ * gab_conv_get_scheme reports CLASSIC meanwhile (it answers for the NEXT streaming launch).
+ * Other power-of-two buffer sizes (32..2048) and responses up to 16384 taps run the fused
+ * uniform-partition kernel (one cut, no choice); anything else the direct-form last resort.      */
 #define GAB_CONV_SCHEME_CLASSIC 0
 #define GAB_CONV_SCHEME_SPLIT 1
 /* One buffer, a range of the channels (split cut only; first_channel and n_channels multiples of
@@ -164,7 +166,7 @@ int gab_conv_stream_ranges(gab_conv_plan* plan, const float* const* d_in, int n_
                            const int* first_channel, const int* n_channels, const gab_stream_t* streams,
                            int n_ranges, int n_buffers);
 int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);   /* fresh plans only (before the first buffer / after reset) */
-int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);
+int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);   /* the cut the next streaming launch will use */
 #define GAB_CONV_STREAMING_HOST_IO 2  /* the same, d_in / d_out in pinned host memory: identical kernel
                                        * under its own name, so that link-speed launches do not
                                        * mix into per-kernel profiles of the HBM-resident ones    */
@@ -192,14 +194,6 @@ int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
  * Additive: the reference processes one buffer per iteration.                    */
 int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
                            int n_buffers, gab_stream_t stream);
-/* Stateless streaming: the history is the caller's own last eight input buffers
- * (d_previous[0] = the buffer before d_in ... d_previous[7] = eight buffers back; same
- * layout as d_in; a buffer of zeros stands for "before the stream began").  Nothing in
- * the plan is read or written but the spectra, so consecutive buffers may be issued on
- * different streams and overlap on the device.  Same results as gab_conv_process in
- * streaming mode fed the same sequence.  Needs bufsize 512 and 512 < ir_len <= 4096.  */
-int gab_conv_process_windowed(gab_conv_plan* plan, const float* d_in,
-                              const float* const* d_previous, float* d_out, gab_stream_t stream);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
                          size_t* history_bytes);
