@@ -351,6 +351,120 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     st4(n.p + pi, pv[0], pv[1], pv[2], pv[3]);
 }
 
+// ---- small grids: one launch per audio SAMPLE (S leapfrog steps), temporal blocking in a tile ----
+// The reference's own TODO (cuda/bench_fdtd3d.cu:12-13): tiles with halos and several steps per
+// launch.  At its default 52^3 grid a step is shorter than a kernel boundary, so a chain of
+// one-step launches is bound by the boundaries (4.2 us per step).  Here a workgroup owns a
+// TX x TY x TZ tile, loads the tile plus a halo of S cells on every side (clipped to the room),
+// advances that box S steps on its own — the rim goes stale one cell per step, the owned cells are
+// S cells inside it — and stores its tile.  Neighbouring tiles recompute each other's halo cells
+// from the same old fields with the same operations, so the result is bit-identical to S
+// one-step launches (and to the oracle).
+// A thread holds one (x, y) column of the box in registers: p and the three low faces of its BZ
+// cells.  Per step, phase 1 updates the faces (needs p of the x-1 and y-1 columns: LDS; z-1: own
+// registers), phase 2 the pressure (needs the NEW faces of the x+1 and y+1 columns: LDS; z+1: own
+// registers); the high faces are the neighbours' new low faces — the same fmaf the one-step kernels
+// recompute.  Three LDS arrays (p, fx, fy), seven LDS accesses per cell and step.
+template <int TX, int TY, int TZ, int S>
+__global__ __launch_bounds__(((TX + 2 * S) * (TY + 2 * S) + 63) / 64 * 64) void fdtd_sample_tile_kernel(
+    Fields o, Fields n, Grid g, float c1, float c2, float damp, size_t src, size_t rcv,
+    const float* __restrict__ add_next, float* __restrict__ strip_out) {
+    constexpr int BX = TX + 2 * S, BY = TY + 2 * S, BZ = TZ + 2 * S;
+    constexpr int NT = (BX * BY + 63) / 64 * 64;       // threads; those past BX*BY hold columns nobody uses
+    constexpr int LZ = NT;                             // LDS plane pitch: every thread has a slot
+    constexpr int PAD = BX;                            // front pad: the y-1 read of row 0 stays inside
+    __shared__ float sp[PAD + BZ * LZ + BX + 1];
+    __shared__ float sfx[PAD + BZ * LZ + BX + 1];
+    __shared__ float sfy[PAD + BZ * LZ + BX + 1];
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    // owned tile and its box, clipped to the room
+    const int x0 = blockIdx.x * TX, x1 = min(nx, x0 + TX);
+    const int y0 = blockIdx.y * TY, y1 = min(ny, y0 + TY);
+    const int z0 = blockIdx.z * TZ, z1 = min(nz, z0 + TZ);
+    const int bx0 = max(0, x0 - S), by0 = max(0, y0 - S), bz0 = max(0, z0 - S);
+    const int ez = min(nz, z1 + S) - bz0;                              // planes of the box inside the room
+    const int lx = threadIdx.x % BX, ly = threadIdx.x / BX;
+    const int x = bx0 + lx, y = by0 + ly;
+    // The arithmetic below is straight-line for every thread and every register cell: cells outside
+    // the room or the box only ever feed the rim that goes stale anyway (shell cells read no
+    // neighbour), so they need no branches — only clamped load addresses and guarded stores.
+    const int xc = min(x, nx - 1), yc = min(y, ny - 1);
+    // 32-bit element offsets (rooms of this kernel are at most 68^3): one address register per access
+    const int sxy = nx * ny;
+    const int l0 = PAD + ly * BX + lx;                                 // LDS slot of the column at lz = 0
+    const int sx = ny * g.px, sy = (ny + 1) * nx;
+    const int pi0 = bz0 * sxy + yc * nx + xc;                          // p and vz, plane bz0
+    const int ix0 = (bz0 * ny + yc) * g.px + xc;
+    const int iy0 = (bz0 * (ny + 1) + yc) * nx + xc;
+
+    float p[BZ], fx[BZ], fy[BZ], fz[BZ];
+#pragma unroll
+    for (int k = 0; k < BZ; ++k) {
+        const int kc = min(k, ez - 1);
+        p[k] = o.p[pi0 + kc * sxy];
+        fx[k] = o.vx[ix0 + kc * sx];
+        fy[k] = o.vy[iy0 + kc * sy];
+        fz[k] = o.vz[pi0 + kc * sxy];
+    }
+#pragma unroll
+    for (int k = 0; k < BZ; ++k) sp[l0 + k * LZ] = p[k];
+    __syncthreads();
+    const bool shell_xy = x == 0 || x >= nx - 1 || y == 0 || y >= ny - 1;
+    const bool has_xm = lx > 0, has_ym = ly > 0;
+#pragma unroll 1
+    for (int step = 0; step < S; ++step) {
+#pragma unroll
+        for (int k = 0; k < BZ; ++k) {
+            const float ux = __builtin_fmaf(-c1, __fsub_rn(p[k], sp[l0 + k * LZ - 1]), fx[k]);
+            const float uy = __builtin_fmaf(-c1, __fsub_rn(p[k], sp[l0 + k * LZ - BX]), fy[k]);
+            fx[k] = has_xm ? ux : fx[k];
+            fy[k] = has_ym ? uy : fy[k];
+        }
+        // z faces from the thread's own registers (p is not touched in this phase)
+#pragma unroll
+        for (int k = 1; k < BZ; ++k) fz[k] = __builtin_fmaf(-c1, __fsub_rn(p[k], p[k - 1]), fz[k]);
+#pragma unroll
+        for (int k = 0; k < BZ; ++k) {
+            sfx[l0 + k * LZ] = fx[k];
+            sfy[l0 + k * LZ] = fy[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BZ; ++k) {
+            const int z = bz0 + k;
+            const bool shell = shell_xy || z == 0 || z >= nz - 1;
+            const float hx = sfx[l0 + k * LZ + 1], hy = sfy[l0 + k * LZ + BX];
+            const float hz = fz[k + 1 < BZ ? k + 1 : k];
+            const float div = __fadd_rn(__fadd_rn(__fsub_rn(hx, fx[k]), __fsub_rn(hy, fy[k])), __fsub_rn(hz, fz[k]));
+            const float pin = __builtin_fmaf(-c2, div, p[k]);
+            p[k] = shell ? __fmul_rn(p[k], damp) : pin;
+            sp[l0 + k * LZ] = p[k];
+        }
+        __syncthreads();
+    }
+    // ---- store the owned cells; the last step of a sample records the receiver and folds in the
+    // next sample's source, like the one-step kernels
+    if (x < x0 || x >= x1 || y < y0 || y >= y1 || threadIdx.x >= BX * BY) return;
+#pragma unroll
+    for (int k = 0; k < BZ; ++k) {
+        const int z = bz0 + k;
+        if (z >= z0 && z < z1) {
+            const int pi = pi0 + k * sxy, ix = ix0 + k * sx, iy = iy0 + k * sy;
+            float pv = p[k];
+            if (strip_out != nullptr && (size_t)pi == rcv) *strip_out = __fmul_rn(pv, 0.1f);     // FDTD3D_OUTPUT_SCALE
+            if (add_next != nullptr && (size_t)pi == src) pv = __fadd_rn(pv, *add_next);
+            n.p[pi] = pv;
+            n.vx[ix] = fx[k];
+            n.vy[iy] = fy[k];
+            n.vz[pi] = fz[k];
+            // the outermost high faces have no owning cell: carried over
+            if (x == nx - 1) n.vx[ix + 1] = o.vx[ix + 1];
+            if (y == ny - 1) n.vy[iy + nx] = o.vy[iy + nx];
+            if (z == nz - 1) n.vz[pi + sxy] = o.vz[pi + sxy];
+        }
+    }
+}
+
 }  // namespace
 }  // namespace gab
 
@@ -384,6 +498,7 @@ struct gab_fdtd_plan {
     int *d_pos_group_start = nullptr, *d_pos_group_tracks = nullptr;
     bool use_graphs = true;
     bool lds_tiles = true;    // rows wide enough to fill a 32-lane row of the LDS-halo kernel (GAB_FDTD_LDS=0: off)
+    bool sample_tiles = true; // small rooms: one launch per sample, S steps in a tile (GAB_FDTD_TILE=0: off)
     hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
     std::vector<std::pair<FdtdGraphKey, hipGraphExec_t>> graphs;   // small LRU, newest last
 };
@@ -456,6 +571,7 @@ int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin,
     f->z_end = z_end;
     if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
     if (const char* v = getenv("GAB_FDTD_LDS")) f->lds_tiles = atoi(v) != 0;
+    if (const char* v = getenv("GAB_FDTD_TILE")) f->sample_tiles = atoi(v) != 0;
     const size_t nzl = (size_t)(z_end - z_begin);
     f->np = (size_t)P.nx * P.ny * (nzl + 2);
     f->nvx = (size_t)(P.nx + 4) * P.ny * nzl + 4;    // padded pitch, see file header
@@ -603,6 +719,11 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         const size_t src = P.source_z * sxy + (size_t)P.source_y * P.nx + P.source_x;
         const int last = first_sample + n_samples;
 
+        // rooms up to 56 cells wide (where one step is shorter than a kernel boundary) take one
+        // launch per SAMPLE: three steps inside a tile (fdtd_sample_tile_kernel).  Measured per step:
+        // 20^3 2.6 vs 3.8 us, 32^3 2.8 vs 3.7, 52^3 3.55 vs 4.2; at 64^3 the one-step chain wins (4.5 vs 4.6)
+        const bool by_sample = f->sample_tiles && !f->pos_tracks && P.steps_per_sample == 3 && f->z_begin == 0 &&
+                               f->z_end == P.nz && P.nx <= 56 && P.ny <= 56 && P.nz <= 56;
         // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
         if (f->pos_tracks && f->pos_tracks != tracks)
             return gab::bad_arg("gab_fdtd_process: the plan has track positions for a different track count");
@@ -628,6 +749,23 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             // the first sample's source goes straight into the current pressure grid; later
             // ones are folded into the step that precedes them
             gab::fdtd_add_source_kernel<<<1, 64, 0, q>>>(cur.p, src, f->inj, first_sample);
+            if (by_sample) {
+                constexpr int TX = 13, TY = 13, TZ = 4;
+                const gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, 0};
+                const size_t rcv = P.receiver_z * sxy + (size_t)P.receiver_y * P.nx + P.receiver_x;
+                const dim3 grid((P.nx + TX - 1) / TX, (P.ny + TY - 1) / TY, (P.nz + TZ - 1) / TZ);
+                const dim3 block(((TX + 6) * (TY + 6) + 63) / 64 * 64);
+                for (int smp = first_sample; smp < last; ++smp) {
+                    gab::fdtd_sample_tile_kernel<TX, TY, TZ, 3><<<grid, block, 0, q>>>(
+                        cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, 1.0f - P.absorption_coeff, src, rcv,
+                        smp + 1 < last ? f->inj + smp + 1 : nullptr, f->strip + smp);
+                    std::swap(cur, nxt);
+                }
+                dim3 bgrid((n_samples + 127) / 128, tracks);
+                gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
+                                                                n_samples);
+                return;
+            }
             for (int smp = first_sample; smp < last; ++smp) {
                 for (int step = 0; step < P.steps_per_sample; ++step) {
                     const bool closes = step == P.steps_per_sample - 1;
@@ -641,7 +779,8 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
                                                             n_samples);
         };
-        const long launches = 3L + (long)n_samples * P.steps_per_sample;
+        const long swaps = (long)n_samples * (by_sample ? 1 : P.steps_per_sample);
+        const long launches = 3L + swaps;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &cap);
         bool replayed = false;
@@ -675,7 +814,7 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             replayed = true;
         }
         if (!replayed) enqueue(s, f->cur, f->nxt);
-        if (((long)n_samples * P.steps_per_sample) & 1) {
+        if (swaps & 1) {
             std::swap(f->cur, f->nxt);
             std::swap(f->cur_real, f->nxt_real);
         }
