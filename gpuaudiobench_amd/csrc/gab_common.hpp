@@ -14,6 +14,8 @@ namespace gab {
 // Thread-local text of the last failure, surfaced through gab_last_error().
 void set_last_error(const std::string& msg);
 const char* last_error();
+// GAB_OK, or GAB_ERR_UNSUPPORTED with the reason set (gab_runtime.cpp)
+int refuse_unsupported_runtime_mode(const char* who);
 
 // Mirrors the reference's CUDA_CHECK contract (cuda/bench_utils.cuh:248-254):
 // a failing runtime call becomes a std::runtime_error carrying the call text.

@@ -1,12 +1,28 @@
 // gab_runtime.cpp — error text, version and device enumeration for the C ABI.
 #include "gab_common.hpp"
 
+#include <cstdlib>
+
 namespace gab {
 namespace {
 thread_local std::string g_last_error;
 }
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error() { return g_last_error.c_str(); }
+
+// AMD_DIRECT_DISPATCH=0 (the runtime's separate dispatch thread) hung a process of this library in
+// round 1 — which call it was blocked in was not recorded, so the cause is unknown and cannot be
+// ruled out to be the library's own use of null-stream memsets beside non-blocking streams.  Until
+// it is understood, plans refuse to be created in that mode instead of risking a hang.
+int refuse_unsupported_runtime_mode(const char* who) {
+    const char* v = getenv("AMD_DIRECT_DISPATCH");
+    if (v && v[0] == '0' && v[1] == '\0') {
+        set_last_error(std::string(who) + ": AMD_DIRECT_DISPATCH=0 is not supported (a process hang was observed "
+                       "in that runtime mode); unset it");
+        return GAB_ERR_UNSUPPORTED;
+    }
+    return GAB_OK;
+}
 }  // namespace gab
 
 extern "C" {

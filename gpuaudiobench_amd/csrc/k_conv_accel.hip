@@ -975,6 +975,7 @@ extern "C" {
 int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
     return gab::guarded([&]() -> int {
         if (!out) return gab::bad_arg("gab_conv_create: null plan pointer");
+        if (int rc = gab::refuse_unsupported_runtime_mode("gab_conv_create")) return rc;
         if (tracks <= 0 || bufsize <= 0 || ir_len <= 0)
             return gab::bad_arg("gab_conv_create: tracks, bufsize and ir_len must be > 0");
         auto* p = new gab_conv_plan;

@@ -555,6 +555,7 @@ gab::Fields virtual_base(const gab::Fields& real, const gab_fdtd_plan& pl) {
 
 int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin, int z_end, const char* who) {
     if (!out || !params) return gab::bad_arg((std::string(who) + ": null pointer").c_str());
+    if (int rc = gab::refuse_unsupported_runtime_mode(who)) return rc;
     const gab_fdtd_params& P = *params;
     if (P.nx < 3 || P.ny < 3 || P.nz < 3) return gab::bad_arg((std::string(who) + ": grid too small").c_str());
     auto inside = [&](int x, int y, int z) {

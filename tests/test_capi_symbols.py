@@ -61,3 +61,19 @@ def test_product_package_does_not_touch_the_oracle():
                 assert "gab_oracle" not in text and "orc_" not in text, f
     out = os.popen("ldd %s" % LIB).read()
     assert "oracle" not in out
+
+
+def test_plans_refuse_the_runtime_mode_that_hung():
+    """AMD_DIRECT_DISPATCH=0 hung a process in round 1 (cause unknown): plans refuse it with a clear
+    error before any device call — checked in a child process, without a GPU."""
+    import subprocess, sys, os
+    code = ("import ctypes as C, gpuaudiobench_amd as g\n"
+            "h = C.c_void_p()\n"
+            "rc = g.lib.gab_conv_create(C.byref(h), 4, 512, 512)\n"
+            "print(rc, g.lib.gab_last_error().decode())\n")
+    env = dict(os.environ, AMD_DIRECT_DISPATCH="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    rc, text = r.stdout.strip().split(" ", 1)
+    assert int(rc) == -3 and "AMD_DIRECT_DISPATCH" in text

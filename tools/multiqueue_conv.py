@@ -36,11 +36,16 @@ def main():
         inputs = [torch.from_numpy(gab.harness.noise(T * B, seed=42 + i)).to(dev) for i in range(16)]
         out = torch.empty(T * B, dtype=torch.float32, device=dev)
         streams = [torch.cuda.Stream() for _ in range(8)]
-        for R in (1, 2, 4, 8):
+        for R in (1, 2, 3, 4, 8):
             if T // R < 64:
                 continue
-            n = T // R
-            ranges = [(r * n, n) for r in range(R)]
+            if R == 3:                       # 16-channel granules (whole XCD groups of workgroups)
+                g = T // 16
+                cuts = [0, 16 * ((g + 2) // 3), 16 * ((g + 2) // 3 + (g + 1) // 3), T]
+                ranges = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)]
+            else:
+                n = T // R
+                ranges = [(r * n, n) for r in range(R)]
             for threaded in ((True,) if R == 1 else (True, False)):
                 os.environ["GAB_CONV_RANGE_THREADS"] = "1" if threaded else "0"
                 # the library reads the variable once: it is static there, so single-thread runs use
