@@ -42,7 +42,7 @@ BUFFERS_PER_STEP = 32           # the resident input batch: distinct buffers cyc
 CLOCK_WARM_BUFFERS = 3000       # untimed, besides --warmup: clocks and caches at their running state
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 DEFAULT_STREAMS = 2             # channel ranges per buffer, each on its own stream (1 = one launch per buffer)
-TRAFFIC_SOURCE = "profiles/pmc_traffic.json"
+TRAFFIC_SOURCE = "profiles/r02a_conv_split_pmc_means.json"
 
 
 def cpu_threads():
@@ -257,8 +257,7 @@ def main():
     pmc_file = os.path.join(ROOT, TRAFFIC_SOURCE)
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get(
-                "conv_split_kernel_bytes_per_launch" if plan.scheme == "split" else "conv_overlap_save_kernel_bytes_per_launch")
+            traffic = json.load(open(pmc_file)).get("hbm_traffic_bytes_per_launch") if plan.scheme == "split" else None
         except Exception:
             traffic = None
 
@@ -302,7 +301,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "frac_wall": alg / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of an earlier run, not measured in this one)"
+            "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of an earlier run over one-launch-per-buffer conv_split_kernel; not measured in this run)"
                               if traffic is not None else None,
             "algorithmic_bytes_per_buffer": alg,
             "device_period_us_per_buffer": period_us,

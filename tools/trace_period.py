@@ -20,7 +20,8 @@ args = ap.parse_args()
 rows = [r for r in csv.DictReader(open(args.trace)) if args.kernel in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[-args.last:]
-name = rows[0]["Kernel_Name"].split("(")[0]
+m = __import__("re").search(r"(\w+_kernel)", rows[0]["Kernel_Name"])
+name = m.group(1) if m else rows[0]["Kernel_Name"][:60]
 R = args.per_buffer or (2 if "range" in name else 1)
 st = [int(r["Start_Timestamp"]) for r in rows]
 en = [int(r["End_Timestamp"]) for r in rows]
