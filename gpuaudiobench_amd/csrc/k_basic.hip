@@ -146,13 +146,28 @@ __global__ __launch_bounds__(kBlock) void modal_placeholder_kernel(const float* 
 // LDS, written with tracks along the lanes: out[T*i + t].  A wave's 16 rows are
 // requested back to back (their playheads are wave-uniform scalar loads), so a
 // workgroup pays the pool's miss latency once, not once per batch of four.
+// A row read at an arbitrary 4-byte offset straddles three 128-byte lines per 256 bytes, and the
+// edge lines are also the neighbouring sample tile's: with the tiles of one row group on eight
+// different XCDs every edge line crossed the fabric twice (FETCH_SIZE 1.54x the algorithmic reads).
+// The 1-D grid is therefore walked so that the sample tiles of a track tile are CONSECUTIVE
+// workgroups of ONE XCD (blocks b and b+8 share an XCD): they meet in that XCD's L2.
 __global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict__ pool,
                                                        const int* __restrict__ playheads,
                                                        float* __restrict__ out, int T, int B) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+    const int nst = (B + 63) / 64, ntt = (T + 63) / 64;          // sample tiles, track tiles
+    int st, tt;
+    if ((ntt & 7) == 0) {
+        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+        st = seq % nst;
+        tt = (seq / nst) * 8 + xcd;
+    } else {
+        st = blockIdx.x % nst;
+        tt = blockIdx.x / nst;
+    }
+    const int i0 = st * 64, t0 = tt * 64;
     const bool col_ok = i0 + lane < B;
     float v[16];
 #pragma unroll
@@ -236,7 +251,7 @@ int gab_rndmem(const float* d_pool, const int* d_playheads, float* d_out, int tr
     return gab::guarded([&]() -> int {
         if (!d_pool || !d_playheads || !d_out) return gab::bad_arg("gab_rndmem: null pointer");
         if (tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_rndmem: tracks and bufsize must be > 0");
-        dim3 grid((bufsize + 63) / 64, (tracks + 63) / 64);
+        dim3 grid(((bufsize + 63) / 64) * ((tracks + 63) / 64));
         gab::rndmem_kernel<<<grid, gab::kBlock, 0, gab::as_stream(stream)>>>(d_pool, d_playheads, d_out,
                                                                                tracks, bufsize);
         return gab::launch_status("rndmem_kernel");

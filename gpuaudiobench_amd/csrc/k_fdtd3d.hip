@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
 // The reference's own TODO (cuda/bench_fdtd3d.cu:12-13): tiles with halos and several steps per
 // launch.  At its default 52^3 grid a step is shorter than a kernel boundary, so a chain of
 // one-step launches is bound by the boundaries (4.2 us per step).  Here a workgroup owns a
-// TX x TY x TZ tile, loads the tile plus a halo of S cells on every side (clipped to the room),
+// nx x TY x TZ tile, loads the tile plus a halo of S cells in y and z (clipped to the room),
 // advances that box S steps on its own — the rim goes stale one cell per step, the owned cells are
 // S cells inside it — and stores its tile.  Neighbouring tiles recompute each other's halo cells
 // from the same old fields with the same operations, so the result is bit-identical to S
@@ -365,37 +365,39 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
 // registers), phase 2 the pressure (needs the NEW faces of the x+1 and y+1 columns: LDS; z+1: own
 // registers); the high faces are the neighbours' new low faces — the same fmaf the one-step kernels
 // recompute.  Three LDS arrays (p, fx, fy), seven LDS accesses per cell and step.
-template <int TX, int TY, int TZ, int S>
-__global__ __launch_bounds__(((TX + 2 * S) * (TY + 2 * S) + 63) / 64 * 64) void fdtd_sample_tile_kernel(
+// Tiles span the WHOLE x extent (rooms of this kernel are at most 56 wide) and are cut in y and z
+// only: a box plane is then one contiguous run of every array, so the loads and stores of a wave
+// are whole cache lines (a first version with 13 x 13 x 4 tiles moved six times as many lines as
+// bytes it used and took 9 us per launch).
+template <int TY, int TZ, int S, int NT>
+__global__ __launch_bounds__(NT) void fdtd_sample_tile_kernel(
     Fields o, Fields n, Grid g, float c1, float c2, float damp, size_t src, size_t rcv,
     const float* __restrict__ add_next, float* __restrict__ strip_out) {
-    constexpr int BX = TX + 2 * S, BY = TY + 2 * S, BZ = TZ + 2 * S;
-    constexpr int NT = (BX * BY + 63) / 64 * 64;       // threads; those past BX*BY hold columns nobody uses
+    constexpr int BY = TY + 2 * S, BZ = TZ + 2 * S;
     constexpr int LZ = NT;                             // LDS plane pitch: every thread has a slot
-    constexpr int PAD = BX;                            // front pad: the y-1 read of row 0 stays inside
-    __shared__ float sp[PAD + BZ * LZ + BX + 1];
-    __shared__ float sfx[PAD + BZ * LZ + BX + 1];
-    __shared__ float sfy[PAD + BZ * LZ + BX + 1];
-    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    constexpr int PAD = 64;                            // front / back pad: the y-1 / y+1 reads of the edge rows stay inside
+    __shared__ float sp[PAD + BZ * LZ + PAD];
+    __shared__ float sfx[PAD + BZ * LZ + PAD];
+    __shared__ float sfy[PAD + BZ * LZ + PAD];
+    const int nx = g.nx, ny = g.ny, nz = g.nz;        // nx <= 56 <= PAD
     // owned tile and its box, clipped to the room
-    const int x0 = blockIdx.x * TX, x1 = min(nx, x0 + TX);
-    const int y0 = blockIdx.y * TY, y1 = min(ny, y0 + TY);
-    const int z0 = blockIdx.z * TZ, z1 = min(nz, z0 + TZ);
-    const int bx0 = max(0, x0 - S), by0 = max(0, y0 - S), bz0 = max(0, z0 - S);
+    const int y0 = blockIdx.x * TY, y1 = min(ny, y0 + TY);
+    const int z0 = blockIdx.y * TZ, z1 = min(nz, z0 + TZ);
+    const int by0 = max(0, y0 - S), bz0 = max(0, z0 - S);
     const int ez = min(nz, z1 + S) - bz0;                              // planes of the box inside the room
-    const int lx = threadIdx.x % BX, ly = threadIdx.x / BX;
-    const int x = bx0 + lx, y = by0 + ly;
+    const int x = threadIdx.x % nx, ly = threadIdx.x / nx;
+    const int y = by0 + ly;
     // The arithmetic below is straight-line for every thread and every register cell: cells outside
     // the room or the box only ever feed the rim that goes stale anyway (shell cells read no
     // neighbour), so they need no branches — only clamped load addresses and guarded stores.
-    const int xc = min(x, nx - 1), yc = min(y, ny - 1);
-    // 32-bit element offsets (rooms of this kernel are at most 68^3): one address register per access
+    const int yc = min(y, ny - 1);
+    // 32-bit element offsets: one address register per access
     const int sxy = nx * ny;
-    const int l0 = PAD + ly * BX + lx;                                 // LDS slot of the column at lz = 0
+    const int l0 = PAD + threadIdx.x;                                  // LDS slot of the column at lz = 0 (= PAD + ly*nx + x)
     const int sx = ny * g.px, sy = (ny + 1) * nx;
-    const int pi0 = bz0 * sxy + yc * nx + xc;                          // p and vz, plane bz0
-    const int ix0 = (bz0 * ny + yc) * g.px + xc;
-    const int iy0 = (bz0 * (ny + 1) + yc) * nx + xc;
+    const int pi0 = bz0 * sxy + yc * nx + x;                           // p and vz, plane bz0
+    const int ix0 = (bz0 * ny + yc) * g.px + x;
+    const int iy0 = (bz0 * (ny + 1) + yc) * nx + x;
 
     float p[BZ], fx[BZ], fy[BZ], fz[BZ];
 #pragma unroll
@@ -409,14 +411,14 @@ __global__ __launch_bounds__(((TX + 2 * S) * (TY + 2 * S) + 63) / 64 * 64) void 
 #pragma unroll
     for (int k = 0; k < BZ; ++k) sp[l0 + k * LZ] = p[k];
     __syncthreads();
-    const bool shell_xy = x == 0 || x >= nx - 1 || y == 0 || y >= ny - 1;
-    const bool has_xm = lx > 0, has_ym = ly > 0;
+    const bool shell_xy = x == 0 || x == nx - 1 || y == 0 || y >= ny - 1;
+    const bool has_xm = x > 0, has_ym = ly > 0;
 #pragma unroll 1
     for (int step = 0; step < S; ++step) {
 #pragma unroll
         for (int k = 0; k < BZ; ++k) {
             const float ux = __builtin_fmaf(-c1, __fsub_rn(p[k], sp[l0 + k * LZ - 1]), fx[k]);
-            const float uy = __builtin_fmaf(-c1, __fsub_rn(p[k], sp[l0 + k * LZ - BX]), fy[k]);
+            const float uy = __builtin_fmaf(-c1, __fsub_rn(p[k], sp[l0 + k * LZ - nx]), fy[k]);
             fx[k] = has_xm ? ux : fx[k];
             fy[k] = has_ym ? uy : fy[k];
         }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(((TX + 2 * S) * (TY + 2 * S) + 63) / 64 * 64) void 
         for (int k = 0; k < BZ; ++k) {
             const int z = bz0 + k;
             const bool shell = shell_xy || z == 0 || z >= nz - 1;
-            const float hx = sfx[l0 + k * LZ + 1], hy = sfy[l0 + k * LZ + BX];
+            const float hx = sfx[l0 + k * LZ + 1], hy = sfy[l0 + k * LZ + nx];
             const float hz = fz[k + 1 < BZ ? k + 1 : k];
             const float div = __fadd_rn(__fadd_rn(__fsub_rn(hx, fx[k]), __fsub_rn(hy, fy[k])), __fsub_rn(hz, fz[k]));
             const float pin = __builtin_fmaf(-c2, div, p[k]);
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(((TX + 2 * S) * (TY + 2 * S) + 63) / 64 * 64) void 
     }
     // ---- store the owned cells; the last step of a sample records the receiver and folds in the
     // next sample's source, like the one-step kernels
-    if (x < x0 || x >= x1 || y < y0 || y >= y1 || threadIdx.x >= BX * BY) return;
+    if (y < y0 || y >= y1) return;
 #pragma unroll
     for (int k = 0; k < BZ; ++k) {
         const int z = bz0 + k;
@@ -722,7 +724,7 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
 
         // rooms up to 56 cells wide (where one step is shorter than a kernel boundary) take one
         // launch per SAMPLE: three steps inside a tile (fdtd_sample_tile_kernel).  Measured per step:
-        // 20^3 2.6 vs 3.8 us, 32^3 2.8 vs 3.7, 52^3 3.55 vs 4.2; at 64^3 the one-step chain wins (4.5 vs 4.6)
+        // 20^3 1.98 vs 3.8 us, 32^3 2.11 vs 3.7, 52^3 3.49 vs 4.2, 56^3 3.59; at 64^3 the one-step chain wins
         const bool by_sample = f->sample_tiles && !f->pos_tracks && P.steps_per_sample == 3 && f->z_begin == 0 &&
                                f->z_end == P.nz && P.nx <= 56 && P.ny <= 56 && P.nz <= 56;
         // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
@@ -751,13 +753,14 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             // ones are folded into the step that precedes them
             gab::fdtd_add_source_kernel<<<1, 64, 0, q>>>(cur.p, src, f->inj, first_sample);
             if (by_sample) {
-                constexpr int TX = 13, TY = 13, TZ = 4;
+                constexpr int TY = 4, TZ = 4, NT = 576;             // 56 x (4 + 6) columns fit 576 threads
                 const gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, 0};
                 const size_t rcv = P.receiver_z * sxy + (size_t)P.receiver_y * P.nx + P.receiver_x;
-                const dim3 grid((P.nx + TX - 1) / TX, (P.ny + TY - 1) / TY, (P.nz + TZ - 1) / TZ);
-                const dim3 block(((TX + 6) * (TY + 6) + 63) / 64 * 64);
+                const dim3 grid((P.ny + TY - 1) / TY, (P.nz + TZ - 1) / TZ);
+                const int cols = P.nx * (TY + 6);
+                const dim3 block((cols + 63) / 64 * 64);
                 for (int smp = first_sample; smp < last; ++smp) {
-                    gab::fdtd_sample_tile_kernel<TX, TY, TZ, 3><<<grid, block, 0, q>>>(
+                    gab::fdtd_sample_tile_kernel<TY, TZ, 3, NT><<<grid, block, 0, q>>>(
                         cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, 1.0f - P.absorption_coeff, src, rcv,
                         smp + 1 < last ? f->inj + smp + 1 : nullptr, f->strip + smp);
                     std::swap(cur, nxt);

@@ -26,10 +26,14 @@
 
 int main(int argc, char** argv) {
     int buffers = 3000, guard = 0, chains = 2;
+    unsigned evflags = hipEventDisableTiming;
+    bool one_way = false;       // --one-way: only chain 0 waits (for chain 1's events); chain 1 only records
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--buffers")) buffers = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--guard")) guard = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--release-to-device")) evflags |= hipEventReleaseToDevice;
+        else if (!strcmp(argv[i], "--one-way")) one_way = true;
     }
     const int T = 1024, B = 512, L = 4096, NIN = 8;
     std::vector<gab_conv_plan*> plan(chains);
@@ -56,7 +60,7 @@ int main(int argc, char** argv) {
     const int total = buffers + 500;
     // events[c][i]: recorded on stream c after its launch i
     std::vector<std::vector<hipEvent_t>> ev(chains, std::vector<hipEvent_t>(guard ? total : 0));
-    for (auto& v : ev) for (auto& e : v) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& v : ev) for (auto& e : v) CK(hipEventCreateWithFlags(&e, evflags));
     std::vector<std::atomic<int>> recorded(chains);
     for (auto& a : recorded) a = 0;
 
@@ -66,7 +70,7 @@ int main(int argc, char** argv) {
             th.emplace_back([&, c]() {
                 CK(hipSetDevice(0));
                 for (int i = first; i < first + count; ++i) {
-                    if (guard) {
+                    if (guard && !(one_way && c != 0)) {
                         const int o = (c + 1) % chains, dep = i - guard;
                         if (dep >= 0) {
                             while (recorded[o].load(std::memory_order_acquire) <= dep) std::this_thread::yield();
@@ -74,7 +78,7 @@ int main(int argc, char** argv) {
                         }
                     }
                     GK(gab_conv_process(plan[c], in[c][i % NIN], out[c], GAB_CONV_STREAMING, (gab_stream_t)st[c]));
-                    if (guard) {
+                    if (guard && !(one_way && c == 0)) {
                         CK(hipEventRecord(ev[c][i], st[c]));
                         recorded[c].store(i + 1, std::memory_order_release);
                     }
@@ -91,7 +95,7 @@ int main(int argc, char** argv) {
     auto t2 = std::chrono::steady_clock::now();
     double us = std::chrono::duration<double, std::micro>(t2 - t0).count() / buffers;
     double host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / buffers;
-    printf("{\"chains\": %d, \"guard\": %d, \"us_per_round\": %.3f, \"us_per_1024ch_buffer\": %.3f, \"host_queue_us_per_round\": %.3f}\n",
-           chains, guard, us, us / chains, host_us);
+    printf("{\"release_to_device\": %d, \"one_way\": %d, \"chains\": %d, \"guard\": %d, \"us_per_round\": %.3f, \"us_per_1024ch_buffer\": %.3f, \"host_queue_us_per_round\": %.3f}\n",
+           (int)((evflags & hipEventReleaseToDevice) != 0), (int)one_way, chains, guard, us, us / chains, host_us);
     return 0;
 }
