@@ -316,12 +316,34 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    plan.close()
+    # ---- library yardstick (tools only, a child process; never on the product path): the
+    # reference's pipeline on rocFFT, same GPU, same shape (tools/ubench/library_baseline.cpp)
+    if world == 1 and rank == 0 and not args.no_side_legs:
+        result["library_baseline"] = library_baseline(T, B, L)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    plan.close()
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def library_baseline(T, B, L):
+    exe = os.path.join(ROOT, "tools", "ubench", "bin", "library_baseline")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, str(T), str(B), str(L), "1000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=120)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(line[-1])
+        d["what"] = ("cuda/bench_conv1d_accel.cu:258-304 restated on hipFFT/rocFFT (tools/ubench/library_baseline.cpp): "
+                     "stateless, one N = nextpow2(L+B-1) transform pair per buffer; a yardstick, not the product")
+        return d
+    except Exception as e:              # a missing FFT library must not cost the bench line
+        return {"error": repr(e)[:300]}
 
 
 def side_legs(gab, plan, inputs, out, stream, R, dev, T, B, L, np, torch):
