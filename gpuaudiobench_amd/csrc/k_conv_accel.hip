@@ -180,7 +180,7 @@ __device__ unsigned long long g_split_stamps[2 * 8 * 8192];
         if (sp.debug & 64) {                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                 \
             if (threadIdx.x == 0)                                                              \
-                g_split_stamps[((head & 1) * 8192 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+                g_split_stamps[((head & 1) * 8192 + (sp.debug >> 20) + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
             __builtin_amdgcn_sched_barrier(0);                                                 \
         }                                                                                      \
     } while (0)
@@ -415,8 +415,8 @@ __device__ __forceinline__ void conv_split_buffer(
     GAB_SSTAMP(0);
 #ifdef GAB_ABLATE
     if ((sp.debug & 64) && threadIdx.x == 0) {
-        g_split_stamps[((head & 1) * 8192 + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
-        g_split_stamps[((head & 1) * 8192 + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+        g_split_stamps[((head & 1) * 8192 + (sp.debug >> 20) + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+        g_split_stamps[((head & 1) * 8192 + (sp.debug >> 20) + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
     }
 #endif
     if (far) {
@@ -1302,10 +1302,15 @@ int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in,
         static const int swap_odd = getenv("GAB_CONV_RANGE_SWAP") ? atoi(getenv("GAB_CONV_RANGE_SWAP")) : 0;
         auto chain = [&](int r) -> int {
             hipStream_t s = gab::as_stream(streams[r]);
-            const int flags = (swap_odd && (r & 1)) ? 256 : 0;
+            static const int dbg = getenv("GAB_CONV_SPLIT_DEBUG") ? atoi(getenv("GAB_CONV_SPLIT_DEBUG")) : 0;
+            // diagnostic builds: stamp rows of a range start at its first workgroup (first_channel / 2)
+            static const int stamp_at = getenv("GAB_CONV_STAMP_AT") ? atoi(getenv("GAB_CONV_STAMP_AT")) : -1;
+            const int flags0 = ((swap_odd && (r & 1)) ? 256 : 0) | (dbg & 0xfffff) | ((first_channel[r] / 2) << 20);
             if (r > 0 && phase_ticks > 0)
                 gab::conv_phase_delay_kernel<<<1, 64, 0, s>>>((unsigned)(phase_ticks * r));
             for (int i = 0; i < n_buffers; ++i) {
+                // GAB_CONV_STAMP_AT=i (diagnostic builds): only buffers i and i+1 of the call are stamped
+                const int flags = (stamp_at < 0 || i == stamp_at || i == stamp_at + 1) ? flags0 : (flags0 & ~(64 | 128));
                 int rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
                                       (head0 + i) & (gab::kSlots - 1), s, flags);
                 if (rc) return rc;

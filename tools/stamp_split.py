@@ -9,6 +9,7 @@ sys.path.insert(0, ".")
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 drain = len(sys.argv) > 2 and sys.argv[2] == "drain"
 os.environ["GAB_CONV_SPLIT_DEBUG"] = str(64 + (128 if drain else 0))
+os.environ["GAB_CONV_STAMP_AT"] = "1200"          # range launches: stamp buffers 1200 and 1201 of 2001 (mid-run)
 import gpuaudiobench_amd as gab
 B, L = 512, 4096
 plan = gab.ConvPlan(T, B, L, scheme="split")
@@ -55,3 +56,26 @@ for x in range(8):
     m = xcc == x
     print("xcc %d: %3d wgs (%3d far)  entry median %.2f  end median %.2f max %.2f" % (
         x, m.sum(), (m & far).sum(), np.median(us(prev[m, 0])), np.median(us(prev[m, 5])), us(prev[m, 5]).max()))
+
+# ---- the same plan launched as two channel ranges on two streams (gab_conv_stream_ranges): are the
+# two kernels of a buffer on the device at the same time?  Device-side clock, so no tracer in the way.
+if T % 8 == 0 and len(sys.argv) > 2 and sys.argv[-1] == "ranges":
+    plan.reset()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    halves = [(0, T // 2), (T // 2, T // 2)]
+    plan.stream_ranges(xs, out, halves, streams, 2001)
+    torch.cuda.synchronize()
+    assert fn(buf, 2 * 8192 * 8) == 0
+    st = np.array(buf[:], dtype=np.int64).reshape(2, 8192, 8)[:, :NB]
+    rows = {}
+    for parity, label in ((0, "buffer k"), (1, "buffer k+1")):        # buffers 1200 (head parity 0) and 1201
+        for r, (a, c) in enumerate(halves):
+            blk = st[parity, a // 2:(a + c) // 2]
+            rows[(label, r)] = (blk[:, 0].min(), blk[:, 5].max())
+    t0 = min(v[0] for v in rows.values())
+    print("two range launches per buffer on two streams (device clock, us after the earliest start):")
+    for (label, r), (a, b) in sorted(rows.items(), key=lambda kv: kv[1][0]):
+        print("   %-10s range %d (stream %d): first workgroup starts %6.2f, last store issued %6.2f  (%.2f us)"
+              % (label, r, r, (a - t0) / 100.0, (b - t0) / 100.0, (b - a) / 100.0))
+    for r in (0, 1):
+        print("   stream %d: period %.2f us" % (r, (rows[("buffer k+1", r)][0] - rows[("buffer k", r)][0]) / 100.0))
