@@ -304,6 +304,13 @@ def main():
             "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of an earlier run over one-launch-per-buffer conv_split_kernel; not measured in this run)"
                               if traffic is not None else None,
             "algorithmic_bytes_per_buffer": alg,
+            "launches_in_flight": R,
+            "how": ("one launch per buffer: achieved = algorithmic bytes per launch / launch period (HIP events on the launch stream)"
+                    if R == 1 else
+                    "%d concurrent channel-range launches per buffer: achieved = algorithmic bytes per BUFFER / device period "
+                    "per buffer (HIP events on every range stream, slowest stream); a kernel tracer serialises the streams, so "
+                    "rocprofv3's per-kernel average describes a range kernel running alone — the figure it can confirm is "
+                    "config.one_launch_per_buffer_single_stream" % R),
             "device_period_us_per_buffer": period_us,
             "wall_period_us_per_buffer": wall_us,
         },

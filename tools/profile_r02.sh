@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="--steps 150 --warmup 15 --no-cpu-baseline --no-side-legs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench_s2 -- python3 bench.py $B --streams 2 > $OUT/bench_s2_line.json 2> $OUT/bench_s2.err
-python3 tools/trace_period.py $OUT/bench_s2_kernel_trace.csv --kernel conv_split_range --last 6400 > $OUT/bench_s2_trace_period.json
+python3 tools/trace_period.py $OUT/bench_s2_kernel_trace.csv --kernel conv_split_range --last 6400 --per-buffer 2 > $OUT/bench_s2_trace_period.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench_s1 -- python3 bench.py $B --streams 1 > $OUT/bench_s1_line.json 2> $OUT/bench_s1.err
 python3 tools/trace_period.py $OUT/bench_s1_kernel_trace.csv --kernel "conv_split_kernel" --last 3200 > $OUT/bench_s1_trace_period.json
 rm -f $OUT/bench_s2_kernel_trace.csv $OUT/bench_s1_kernel_trace.csv      # tens of MB; the derived JSON stays
@@ -30,6 +30,12 @@ echo "secondary done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o fdtd128 -- python3 tools/fdtd_loop.py 128 334 128 > $OUT/fdtd128.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o fdtd52 -- python3 tools/fdtd_loop.py 52 512 128 > $OUT/fdtd52.txt 2>&1
 rm -f $OUT/fdtd128_kernel_trace.csv $OUT/fdtd52_kernel_trace.csv
+# device-clock view of the two range streams (diagnostic build with phase stamps; no tracer attached)
+if [ -f gpuaudiobench_amd/libgab_hip_ablate.so ]; then
+  GAB_LIB_PATH=$PWD/gpuaudiobench_amd/libgab_hip_ablate.so python3 tools/stamp_split.py 1024 x ranges > $OUT/stamps_split.txt 2>&1
+fi
+bash tools/ablate_sweep.sh > $OUT/ablations.txt 2>&1
+python3 tools/multiqueue_conv.py --buffers 4000 > $OUT/multiqueue.jsonl 2>/dev/null
 tools/ubench/bin/library_baseline > $OUT/library_baseline.json
 tools/ubench/bin/mfma_dft > $OUT/mfma_dft.jsonl
 ls $OUT
