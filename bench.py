@@ -42,7 +42,7 @@ BUFFERS_PER_STEP = 32           # the resident input batch: distinct buffers cyc
 CLOCK_WARM_BUFFERS = 3000       # untimed, besides --warmup: clocks and caches at their running state
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 DEFAULT_STREAMS = 2             # channel ranges per buffer, each on its own stream (1 = one launch per buffer)
-TRAFFIC_SOURCE = "profiles/r02a_conv_split_pmc_means.json"
+TRAFFIC_SOURCE = "profiles/r02b_conv_split_pmc_means.json"
 
 
 def cpu_threads():
