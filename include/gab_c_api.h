@@ -156,12 +156,19 @@ typedef struct gab_conv_plan gab_conv_plan;
  * 4): the same launch on offset base pointers; d_in / d_out are the whole buffers.  Disjoint ranges
  * may go to different streams — channels are independent, so each stream is its own chain of
  * launches and the chains overlap each other's kernel boundaries.  gab_conv_advance moves the
- * plan's ring position: once per buffer, after all its ranges have been queued.                 */
+ * plan's ring position: once per buffer, after all its ranges have been queued.
+ * Ordering: consecutive buffers of a channel range must be ordered by the caller (the same stream
+ * for that range every buffer, or events) — the library only orders gab_conv_reset against launches
+ * on other streams (it records / waits events itself; no host synchronisation is needed around a
+ * reset).  Launch errors are reported by the call that queued the launch.                          */
 int gab_conv_process_range(gab_conv_plan* plan, const float* d_in, float* d_out, int first_channel,
                            int n_channels, gab_stream_t stream);
 int gab_conv_advance(gab_conv_plan* plan);
 /* The loop around the two calls above, for n_buffers consecutive buffers (input i = d_in[i % n_in],
- * all into d_out): range r of every buffer goes to streams[r].                                   */
+ * all into d_out): range r of every buffer goes to streams[r].  With more than one range every range
+ * gets its own host thread for the duration of the call (a launch costs the host 3-4 us; one thread
+ * cannot feed two streams at the rate the device runs them).  Ranges must not overlap.  Returns
+ * when everything is QUEUED; the streams are the caller's to synchronise.                         */
 int gab_conv_stream_ranges(gab_conv_plan* plan, const float* const* d_in, int n_in, float* d_out,
                            const int* first_channel, const int* n_channels, const gab_stream_t* streams,
                            int n_ranges, int n_buffers);

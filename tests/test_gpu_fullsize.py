@@ -247,3 +247,48 @@ def test_fdtd_wide_slab_cut_developed_field(gab, orc):
     assert np.count_nonzero(ref.reshape(T, B)[0]) > 60
     for s in slabs:
         s.close()
+
+
+def test_conv_accel_mixed_launch_paths_stay_bit_identical(gab, orc):
+    """A random mix of the ways a streaming buffer can be launched — one launch, two range launches
+    on two streams + advance, the threaded library loop over 1-4 buffers, resets in between, no host
+    synchronisation except where a result is read — walks the same history as a plan that only ever
+    sees gab_conv_process: same bits, every buffer."""
+    import torch
+    T, B, L = 256, 512, 4096
+    ir = dev(orc.conv_accel_ir(L, T))
+    ref, mix = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    ref.set_ir(ir)
+    mix.set_ir(ir)
+    xs = [dev(orc.noise(T * B, seed=5000 + i)) for i in range(6)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    rng = np.random.default_rng(11)
+    out = torch.empty(T * B, device="cuda")
+    n = 0
+    for step in range(60):
+        how = int(rng.integers(0, 5))
+        if how == 4 and step > 0:
+            ref.reset()
+            mix.reset()
+            continue
+        count = int(rng.integers(1, 5)) if how == 3 else 1
+        for j in range(count):
+            want = ref.process(xs[(n + j) % 6], mode=gab.CONV_STREAMING)
+        if how == 0:
+            mix.process(xs[n % 6], out=out, mode=gab.CONV_STREAMING)
+        elif how in (1, 2):
+            cut = 4 * int(rng.integers(1, T // 4))
+            mix.process_range(xs[n % 6], out, 0, cut, stream=streams[0])
+            mix.process_range(xs[n % 6], out, cut, T - cut, stream=streams[1 + (how == 2)])
+            mix.advance()
+        else:
+            third = 4 * (T // 12)
+            ranges = [(0, third), (third, third), (2 * third, T - 2 * third)]
+            # inputs cycle from index n: rotate the list so that buffer i of the call is xs[(n + i) % 6]
+            rot = [xs[(n + i) % 6] for i in range(6)]
+            mix.stream_ranges(rot, out, ranges, streams, count)
+        n += count
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(host(out)), bits(host(want))), (step, how)
+    ref.close()
+    mix.close()
