@@ -292,3 +292,32 @@ def test_conv_accel_mixed_launch_paths_stay_bit_identical(gab, orc):
         assert np.array_equal(bits(host(out)), bits(host(want))), (step, how)
     ref.close()
     mix.close()
+
+
+@pytest.mark.parametrize("nx,ny,nz,samples", [
+    (48, 20, 36, 30),      # one launch per sample (tile kernel), clipped boxes on every side
+    (52, 33, 7, 24),       # fewer planes than a box is tall; odd row count
+    (21, 56, 40, 20),      # rows that are not a multiple of 4 cells
+    (100, 72, 36, 12),     # LDS-halo step kernel, non-cubic
+    (36, 100, 24, 12),     # wider than 56 in y only: one launch per step
+])
+def test_fdtd_non_cubic_rooms_bit_exact(gab, orc, nx, ny, nz, samples):
+    """Rooms that are not cubes (the reference's parameters are per axis, bench_fdtd3d.cuh:68-86):
+    every kernel form, output and pressure field bit-exact, state carried across two calls."""
+    import torch
+    T, B = 5, samples
+    P = orc.fdtd_params(nx, ny, nz)
+    G = gab.fdtd_default_params(nx, ny, nz)
+    x = orc.Rand(7).bipolar(T * B)
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    plan = gab.FdtdPlan(G)
+    out = torch.zeros(T * B, device="cuda")
+    half = samples // 2
+    for first, cnt in ((0, half), (half, samples - half)):
+        orc.fdtd(P, grids, x, ref, T, B, first, cnt, fused=True)
+        plan.process(dev(x), out, T, B, first, cnt)
+    assert np.array_equal(bits(host(out)), bits(ref))
+    assert np.array_equal(bits(host(plan.pressure()).ravel()), bits(grids[0]))
+    assert np.abs(grids[0]).max() > 0
+    plan.close()
