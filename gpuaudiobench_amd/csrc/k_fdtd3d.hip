@@ -416,6 +416,17 @@ __global__ __launch_bounds__(NT) void fdtd_sample_tile_kernel(
         fy[k] = o.vy[iy0 + kc * sy];
         fz[k] = o.vz[pi0 + kc * sxy];
     }
+    // the outermost high faces have no owning cell and are carried over: requested here, with
+    // everything else, so that their latency is not paid after the last step
+    const bool own_y = y >= y0 && y < y1;
+    float cx[BZ], cy[BZ], cz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < BZ; ++k) {
+        const int kc = min(k, ez - 1);
+        cx[k] = (own_y && x == nx - 1) ? o.vx[ix0 + kc * sx + 1] : 0.0f;
+        cy[k] = (own_y && y == ny - 1) ? o.vy[iy0 + kc * sy + nx] : 0.0f;
+    }
+    if (own_y && z1 == nz) cz = o.vz[pi0 + (nz - bz0) * sxy];
 #pragma unroll
     for (int k = 0; k < BZ; ++k) sp[l0 + k * LZ] = p[k];
     __syncthreads();
@@ -467,10 +478,9 @@ __global__ __launch_bounds__(NT) void fdtd_sample_tile_kernel(
             n.vx[ix] = fx[k];
             n.vy[iy] = fy[k];
             n.vz[pi] = fz[k];
-            // the outermost high faces have no owning cell: carried over
-            if (x == nx - 1) n.vx[ix + 1] = o.vx[ix + 1];
-            if (y == ny - 1) n.vy[iy + nx] = o.vy[iy + nx];
-            if (z == nz - 1) n.vz[pi + sxy] = o.vz[pi + sxy];
+            if (x == nx - 1) n.vx[ix + 1] = cx[k];
+            if (y == ny - 1) n.vy[iy + nx] = cy[k];
+            if (z == nz - 1) n.vz[pi + sxy] = cz;
         }
     }
 }
