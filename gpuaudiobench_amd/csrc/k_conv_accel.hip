@@ -1330,12 +1330,21 @@ int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in,
             std::vector<int> rcs(n_ranges, GAB_OK);
             std::vector<std::string> errs(n_ranges);
             std::vector<std::thread> workers;
-            for (int r = 1; r < n_ranges; ++r)
-                workers.emplace_back([&, r]() {
-                    if (hipSetDevice(p->device) != hipSuccess) { rcs[r] = GAB_ERR_RUNTIME; errs[r] = "hipSetDevice failed"; return; }
+            workers.reserve(n_ranges);
+            bool spawn_failed = false;
+            for (int r = 1; r < n_ranges && !spawn_failed; ++r) {
+                try {
+                    workers.emplace_back([&, r]() {
+                        if (hipSetDevice(p->device) != hipSuccess) { rcs[r] = GAB_ERR_RUNTIME; errs[r] = "hipSetDevice failed"; return; }
+                        rcs[r] = chain(r);
+                        if (rcs[r]) errs[r] = gab::last_error();      // the error text is thread-local
+                    });
+                } catch (const std::exception& e) {               // no thread to be had: this range is queued from here
+                    spawn_failed = true;
                     rcs[r] = chain(r);
-                    if (rcs[r]) errs[r] = gab::last_error();      // the error text is thread-local
-                });
+                    for (int q = r + 1; q < n_ranges; ++q) rcs[q] = chain(q);
+                }
+            }
             rcs[0] = chain(0);
             for (auto& w : workers) w.join();
             for (int r = 0; r < n_ranges; ++r)
