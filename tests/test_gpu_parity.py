@@ -758,8 +758,11 @@ def test_fdtd_slab_argument_errors(gab):
     s.close()
 
 
-def test_rndmem_small_pool(gab, orc):
-    T, B, N = 130, 512, 1 << 20
+@pytest.mark.parametrize("T,B", [(130, 512), (1024, 512), (512, 200), (4096, 64), (2048, 1000)])
+def test_rndmem_small_pool(gab, orc, T, B):
+    """Track counts whose tile count is a multiple of eight walk the grid XCD-locally (rndmem_kernel);
+    the others in plain order: both bit-exact, over three buffers of advancing playheads."""
+    N = 1 << 20
     pool = orc.rndmem_pool(N)
     ph, st, en = orc.rndmem_playheads(T, B, pool_elems=N)
     pd = dev(pool)
