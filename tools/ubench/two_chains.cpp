@@ -13,6 +13,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,12 +29,14 @@ int main(int argc, char** argv) {
     int buffers = 3000, guard = 0, chains = 2;
     unsigned evflags = hipEventDisableTiming;
     bool one_way = false;       // --one-way: only chain 0 waits (for chain 1's events); chain 1 only records
+    bool value_ops = false;     // --value-ops: guards as hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--buffers")) buffers = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--guard")) guard = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--release-to-device")) evflags |= hipEventReleaseToDevice;
         else if (!strcmp(argv[i], "--one-way")) one_way = true;
+        else if (!strcmp(argv[i], "--value-ops")) value_ops = true;
     }
     const int T = 1024, B = 512, L = 4096, NIN = 8;
     std::vector<gab_conv_plan*> plan(chains);
@@ -63,6 +66,12 @@ int main(int argc, char** argv) {
     for (auto& v : ev) for (auto& e : v) CK(hipEventCreateWithFlags(&e, evflags));
     std::vector<std::atomic<int>> recorded(chains);
     for (auto& a : recorded) a = 0;
+    std::vector<uint32_t*> flag(chains, nullptr);
+    if (value_ops)
+        for (int c = 0; c < chains; ++c) {
+            CK(hipExtMallocWithFlags((void**)&flag[c], 8, hipMallocSignalMemory));
+            CK(hipMemset(flag[c], 0, 8));
+        }
 
     auto run = [&](int first, int count) {
         std::vector<std::thread> th;
@@ -72,15 +81,21 @@ int main(int argc, char** argv) {
                 for (int i = first; i < first + count; ++i) {
                     if (guard && !(one_way && c != 0)) {
                         const int o = (c + 1) % chains, dep = i - guard;
-                        if (dep >= 0) {
+                        if (dep >= 0 && value_ops) {
+                            CK(hipStreamWaitValue32(st[c], flag[o], (uint32_t)(dep + 1), hipStreamWaitValueGte, 0xffffffffu));
+                        } else if (dep >= 0) {
                             while (recorded[o].load(std::memory_order_acquire) <= dep) std::this_thread::yield();
                             CK(hipStreamWaitEvent(st[c], ev[o][dep], 0));
                         }
                     }
                     GK(gab_conv_process(plan[c], in[c][i % NIN], out[c], GAB_CONV_STREAMING, (gab_stream_t)st[c]));
                     if (guard && !(one_way && c == 0)) {
-                        CK(hipEventRecord(ev[c][i], st[c]));
-                        recorded[c].store(i + 1, std::memory_order_release);
+                        if (value_ops) {
+                            CK(hipStreamWriteValue32(st[c], flag[c], (uint32_t)(i + 1), 0));
+                        } else {
+                            CK(hipEventRecord(ev[c][i], st[c]));
+                            recorded[c].store(i + 1, std::memory_order_release);
+                        }
                     }
                 }
             });
@@ -95,7 +110,7 @@ int main(int argc, char** argv) {
     auto t2 = std::chrono::steady_clock::now();
     double us = std::chrono::duration<double, std::micro>(t2 - t0).count() / buffers;
     double host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / buffers;
-    printf("{\"release_to_device\": %d, \"one_way\": %d, \"chains\": %d, \"guard\": %d, \"us_per_round\": %.3f, \"us_per_1024ch_buffer\": %.3f, \"host_queue_us_per_round\": %.3f}\n",
-           (int)((evflags & hipEventReleaseToDevice) != 0), (int)one_way, chains, guard, us, us / chains, host_us);
+    printf("{\"value_ops\": %d, \"release_to_device\": %d, \"one_way\": %d, \"chains\": %d, \"guard\": %d, \"us_per_round\": %.3f, \"us_per_1024ch_buffer\": %.3f, \"host_queue_us_per_round\": %.3f}\n",
+           (int)value_ops, (int)((evflags & hipEventReleaseToDevice) != 0), (int)one_way, chains, guard, us, us / chains, host_us);
     return 0;
 }
