@@ -641,6 +641,178 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
                                        (head + nb) & (kSlots - 1), lds);
 }
 
+// ---- split cut, n buffers per launch: both roles of a duo in ONE resident workgroup -----------------
+// gab_conv_process_batch on a split plan.  A workgroup of 512 threads owns a duo for the whole launch:
+// waves 0-3 run the near role (as conv_split_kernel's near workgroups do), waves 4-7 the far role of
+// the pair whose turn it is; the far share they park is picked up by their own near waves one and two
+// buffers later, so nothing crosses workgroups and the launch needs no boundary between buffers —
+// workgroups drift apart instead of loading and computing in lockstep.  The two roles share the
+// workgroup's one hardware barrier: per buffer every wave executes exactly kBatchBarriers s_barriers
+// (the far role's five are those of its transforms; the near role has two of its own and three
+// placed where the far role's fall in time), plus one that closes the buffer.  Same arithmetic, same
+// order as conv_split_kernel: bit-identical to n launches of it.
+constexpr int kBatchBarriers = 5;      // per buffer and wave, before the closing one
+
+__global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
+    __shared__ cf lds[4 * kWaveImg + 2 * kLdsHalf];
+    const int tid = threadIdx.x;
+    const bool far = tid >= kThreads;                                 // uniform per wave
+    const int d = xcd_contiguous(blockIdx.x, gridDim.x);
+    const size_t step = (size_t)T * kB;
+
+    if (far) {
+        const int ft = tid - kThreads;
+        using FB = fft::BlockFFT<kNB, 16, false>;
+        using FBi = fft::BlockFFT<kNB, 16, true>;
+        cf* const X = lds + 4 * kWaveImg;
+        cf* const Y = X + kLdsHalf;
+        typename FB::Twiddles twb;
+        FB::load_twiddles(twb, tw, ft);
+        for (int nb = 0; nb < n_buffers; ++nb) {
+            const int head = (head0 + nb) & (kSlots - 1);
+            const float* const inb = in + nb * step;
+            const int q = 2 * d + (head & 1);
+            const int ta = 2 * q, tb = ta + 1;
+            const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
+            cf* const cp = sp.carry + (size_t)q * kCarrySlots * kB;
+            cf zb[16];
+            {
+                const float* xa = inb + (size_t)ta * kB;
+                const float* xb = inb + (size_t)tb * kB;
+                zb[14] = mk(xa[ft], xb[ft]);
+                zb[15] = mk(xa[ft + kThreads], xb[ft + kThreads]);
+            }
+#pragma unroll
+            for (int r = 0; r < 14; ++r)                              // blocks k-7 .. k-1, oldest first
+                zb[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
+            __builtin_amdgcn_sched_barrier(0);
+            float4 cb[16];
+            load_spectra<kNB, 16>(cb, sp.pmF + (size_t)q * kBinsB, ft);
+            __builtin_amdgcn_sched_barrier(0);
+            FB::run(zb, X, Y, twb, ft);                               // 2 barriers
+            cf zpb[16];
+            partner_exchange<kNB, 16, true>(zb, zpb, X, ft);          // 1 barrier
+            spectral_product<kNB, 16>(zb, zpb, cb, ft);
+            FBi::template run<typename FB::Twiddles, 4>(zb, Y, X, twb, ft);     // 2 barriers; only [12..15]
+            cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;          // block k+1
+            cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;          // block k+2
+            c1[ft] = zb[12];
+            c1[ft + kThreads] = zb[13];
+            c2[ft] = zb[14];
+            c2[ft + kThreads] = zb[15];
+            __syncthreads();                                          // closes the buffer
+        }
+        return;
+    }
+
+    // ---- near waves: wave w holds one 1024-point transform: pair (w >> 1) of the duo, window w & 1
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = 2 * d + (w >> 1);
+    const int ta = 2 * q, tb = ta + 1;
+    const bool second = (w & 1) != 0;
+    cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+    cf* const img = lds + w * kWaveImg;
+    using WF = fft::WaveFFT1024<false>;
+    using WFi = fft::WaveFFT1024<true>;
+    WF::Twiddles t;
+    WF::load_twiddles(t, tw, lane);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    const float4* const pm = (second ? sp.pmA2 : pmA) + (size_t)q * kBinsA;
+    for (int nb = 0; nb < n_buffers; ++nb) {
+        const int head = (head0 + nb) & (kSlots - 1);
+        const float* const inb = in + nb * step;
+        float* const outb = out + nb * step;
+        const int s1 = ((head + kSlots - 1) & (kSlots - 1)) * kB;     // block k-1
+        const int s2 = ((head + kSlots - 2) & (kSlots - 1)) * kB;     // block k-2
+        cf z[16];
+        if (!second) {
+            const float* xa = inb + (size_t)ta * kB;
+            const float* xb = inb + (size_t)tb * kB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[8 + j] = mk(xa[lane + 64 * j], xb[lane + 64 * j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = hp[s1 + lane + 64 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[8 + j] = hp[s1 + lane + 64 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float4 c[16];
+        load_spectra<kNA, 16>(c, pm, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!second) {                                                // the new block enters the ring
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = z[8 + j];
+        }
+        __syncthreads();                                              // (1) beside the far role's first pass
+        WF::run(z, img, t, lane);
+        __syncthreads();                                              // (2) beside its second pass
+        {
+            cf zp[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+            spectral_product<kNA, 16>(z, zp, c, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (second) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+        }
+        __syncthreads();                                              // (3) the A2 products are in LDS
+        cf y[8];
+        if (!second) {
+            const cf* const other = img + kWaveImg;                   // the A2 transform of the same pair
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = fft::cadd(z[r], other[rb + 68 * r]);
+        }
+        __syncthreads();                                              // (4) beside the far role's inverse
+        if (!second) {
+            const cf* const cy = sp.carry + ((size_t)q * kCarrySlots + (head & (kCarrySlots - 1))) * kB;
+            cf park[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) park[j] = cy[lane + 64 * j];
+            WFi::run(z, img, t, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+            if (w == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[4 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
+            }
+        }
+        __syncthreads();                                              // (5) the swapped halves are in LDS
+        if (!second) {
+            float* const o0 = outb + 4 * (size_t)d;
+            if (w == 0) {
+                const cf* const other = lds + 2 * kWaveImg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const cf theirs = other[lane + 64 * j];
+                    *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * j)) = make_float4(y[j].x, y[j].y, theirs.x, theirs.y);
+                }
+            } else {
+                const cf* const other = lds;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const cf theirs = other[lane + 64 * j];
+                    *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * (4 + j))) = make_float4(theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                }
+            }
+        }
+        __syncthreads();                                              // closes the buffer
+    }
+}
+
 // Occupies one wave for about `ticks` of the 100 MHz real-time counter: offsets the phase of a chain
 // of launches against the chains on other streams (gab_conv_stream_ranges).
 __global__ void conv_phase_delay_kernel(unsigned ticks) {
@@ -1372,6 +1544,19 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
         if (!p->ir_set) return gab::bad_arg("gab_conv_process_batch: gab_conv_set_ir has not been called");
         if (n_buffers <= 0) return gab::bad_arg("gab_conv_process_batch: n_buffers must be > 0");
         hipStream_t s = gab::as_stream(stream);
+        if (p->fused && p->split && p->split_live) {
+            // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches,
+            // and the plan stays on the split cut afterwards
+            p->order_after_reset(s);
+            gab::ConvSplit sp{p->pmA2, p->pmF, p->carry, 0};
+            gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(2 * gab::kThreads), 0, s>>>(
+                d_in, d_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n_buffers);
+            int rc = gab::launch_status("conv_split_batch_kernel");
+            if (rc) return rc;
+            p->head = (p->head + n_buffers) & (gab::kSlots - 1);
+            p->fresh = false;
+            return GAB_OK;
+        }
         if (p->fused && p->tail) {
             gab::conv_batch_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
                 d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head, n_buffers);

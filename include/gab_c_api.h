@@ -145,9 +145,9 @@ typedef struct gab_conv_plan gab_conv_plan;
  *   SPLIT    taps [0,512) + [512,1024) + [1024,4096): the far partition runs for a pair every
  *            other buffer, one buffer ahead, on its own workgroups (conv_split_kernel).  Same
  *            convolution, different rounding: results agree to ~1e-7 of the peak, not bit for bit.
- * gab_conv_process_batch and host-io launches always use the CLASSIC cut; after a batch or host-io
- * call a SPLIT plan continues with CLASSIC launches until the next gab_conv_reset, and
- * gab_conv_get_scheme reports CLASSIC meanwhile (it answers for the NEXT streaming launch).
+ * Host-io launches always use the CLASSIC cut; after one a SPLIT plan continues with CLASSIC
+ * launches until the next gab_conv_reset, and gab_conv_get_scheme reports CLASSIC meanwhile (it
+ * answers for the NEXT streaming launch).  gab_conv_process_batch uses the plan's current cut.
  * Other power-of-two buffer sizes (32..2048) and responses up to 16384 taps run the fused
  * uniform-partition kernel (one cut, no choice); anything else the direct-form last resort.      */
 #define GAB_CONV_SCHEME_CLASSIC 0
@@ -195,10 +195,12 @@ int gab_conv_reset(gab_conv_plan* plan, gab_stream_t stream);
 int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
                      int mode, gab_stream_t stream);
 /* n_buffers consecutive buffers in ONE launch (streaming mode): d_in = [n][T*B]
- * track-major buffers back to back, d_out = [n][B*T].  Same results as n calls of
- * gab_conv_process; for callers that have the input ahead of time (offline
- * rendering): no kernel boundary between buffers, spectra stay cache-resident.
- * Additive: the reference processes one buffer per iteration.                    */
+ * track-major buffers back to back, d_out = [n][B*T].  Same results, bit for bit, as n calls of
+ * gab_conv_process on the plan's current cut; for callers that have the input ahead of time
+ * (offline rendering): no kernel boundary between buffers.  On the split cut a 512-thread
+ * workgroup owns a duo of channel pairs for the whole launch, near role on four waves, far role on
+ * the other four (conv_split_batch_kernel).  Additive: the reference processes one buffer per
+ * iteration.                                                                     */
 int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
                            int n_buffers, gab_stream_t stream);
 /* Bytes of device state the plan holds: spectra, history.                    */

@@ -340,21 +340,29 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
     b.close()
 
 
-@pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (5, 512, 2000, 3), (16, 512, 512, 4), (3, 256, 700, 5)])
+@pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
+                                      (16, 512, 512, 4), (3, 256, 700, 5)])
 def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
-    """gab_conv_process_batch: n buffers in one launch walk the same history as n launches of the
-    classic cut — same bits — including across two batches and for shapes that take the fallback."""
+    """gab_conv_process_batch: n buffers in one launch walk the same history as n launches — same
+    bits — including across two batches, mixed with single launches, and for shapes that take other
+    kernels.  A plan on the split cut batches with the split cut (conv_split_batch_kernel: both roles
+    of a duo in one resident workgroup) and stays on it; other plans batch with the classic cut."""
     import torch
     ir = dev(orc.conv_accel_ir(L, T))
-    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L)
+    b = gab.ConvPlan(T, B, L)
+    a = gab.ConvPlan(T, B, L, scheme=b.scheme if B == 512 and L <= 4096 else None)
     a.set_ir(ir)
     b.set_ir(ir)
-    x = np.concatenate([orc.noise(T * B, seed=60 + i) for i in range(2 * n)])
+    scheme = b.scheme
+    x = np.concatenate([orc.noise(T * B, seed=60 + i) for i in range(2 * n + 2)])
     seq = np.concatenate([host(a.process(dev(x[i * T * B:(i + 1) * T * B]), mode=gab.CONV_STREAMING))
-                          for i in range(2 * n)])
+                          for i in range(2 * n + 2)])
     y1 = host(b.process_batch(dev(x[:n * T * B]), n))
-    y2 = host(b.process_batch(dev(x[n * T * B:]), n))
-    assert np.array_equal(bits(seq), bits(np.concatenate([y1, y2])))
+    ym = host(b.process(dev(x[n * T * B:(n + 1) * T * B]), mode=gab.CONV_STREAMING))       # a single launch in between
+    y2 = host(b.process_batch(dev(x[(n + 1) * T * B:(2 * n + 1) * T * B]), n))
+    yl = host(b.process(dev(x[(2 * n + 1) * T * B:]), mode=gab.CONV_STREAMING))
+    assert np.array_equal(bits(seq), bits(np.concatenate([y1, ym, y2, yl])))
+    assert b.scheme == scheme                             # a batch call does not change the plan's cut
     with pytest.raises(gab.GabError):
         lib_rc = gab.lib.gab_conv_process_batch(b._h, None, None, 1, None)
         gab.check(lib_rc)
@@ -365,9 +373,9 @@ def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
 def test_conv_accel_split_and_classic_streams_agree(gab, orc):
     """The split cut (far partition every other buffer, one buffer ahead, on its own workgroups)
     and the classic cut are the same convolution: 30 buffers agree to rounding, against each other
-    and against the float64 direct form; a batch call in the middle of a split stream (which
-    moves the history ring without the carry ring) is followed by classic launches that stay
-    correct, and a reset brings the split launches back."""
+    and against the float64 direct form, with a batch call in the middle of both streams; a host-io
+    launch (which moves the history ring without the carry ring) is followed by classic launches
+    that stay correct, and a reset brings the split launches back."""
     import torch
     T, B, L = 64, 512, 4096
     ir = orc.conv_accel_ir(L, T)
@@ -393,9 +401,18 @@ def test_conv_accel_split_and_classic_streams_agree(gab, orc):
             assert np.abs(ya - ref).max() <= 1e-5 * peak, i
             assert np.abs(yb - ref).max() <= 1e-5 * peak, i
             assert np.abs(ya - yb).max() <= 2e-6 * peak, i
-        if i >= 21:
-            assert np.array_equal(bits(ya), bits(yb)), i          # b runs classic launches now
-            assert b.scheme == "classic"                          # ... and says so (the NEXT launch's cut)
+        assert b.scheme == "split"                                # also after the batch call
+    # a host-io launch (pinned buffers) uses the classic cut and leaves the plan on it until a reset
+    hx = torch.from_numpy(xs[0]).pin_memory()
+    hy = torch.empty(T * B).pin_memory()
+    b.process(hx, out=hy, mode=gab.CONV_STREAMING)
+    ya = host(a.process(dev(xs[0]), mode=gab.CONV_STREAMING))
+    torch.cuda.synchronize()
+    assert b.scheme == "classic"                      # ... and says so (the NEXT launch's cut)
+    assert np.abs(hy.numpy() - ya).max() <= 2e-6 * peak
+    ya = host(a.process(dev(xs[1]), mode=gab.CONV_STREAMING))
+    yb = host(b.process(dev(xs[1]), mode=gab.CONV_STREAMING))
+    assert np.abs(ya - yb).max() <= 2e-6 * peak
     # prepared arguments (what bench.py's timed loop uses) are the same call
     args = b.prepare(dev(xs[0]), torch.empty(T * B, device="cuda"))
     b.launch(args)
