@@ -661,6 +661,10 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
     const bool far = tid >= kThreads;                                 // uniform per wave
     const int d = xcd_contiguous(blockIdx.x, gridDim.x);
     const size_t step = (size_t)T * kB;
+    // Inputs of the launch are all there, so the two newest blocks of any window come straight from
+    // the input buffers (the ring only serves older blocks, and the launches that follow), and each
+    // role requests the NEXT buffer's operands as soon as its spectral product has freed the registers
+    // (partner values, spectra): the loads fly under the inverse transform.
 
     if (far) {
         const int ft = tid - kThreads;
@@ -668,34 +672,47 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
         using FBi = fft::BlockFFT<kNB, 16, true>;
         cf* const X = lds + 4 * kWaveImg;
         cf* const Y = X + kLdsHalf;
-        typename FB::Twiddles twb;
+        // powers of the first twiddled pass are re-formed in the pass (the same products, the same
+        // values): the registers hold the next window instead
+        typename FB::Mixed twb;
         FB::load_twiddles(twb, tw, ft);
-        for (int nb = 0; nb < n_buffers; ++nb) {
+        // window of buffer nb for the pair whose turn it is: blocks k-7 .. k, oldest first
+        auto load_window = [&](int nb, cf (&z)[16], float4 (&c)[16]) {
             const int head = (head0 + nb) & (kSlots - 1);
-            const float* const inb = in + nb * step;
             const int q = 2 * d + (head & 1);
-            const int ta = 2 * q, tb = ta + 1;
             const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
-            cf* const cp = sp.carry + (size_t)q * kCarrySlots * kB;
-            cf zb[16];
-            {
-                const float* xa = inb + (size_t)ta * kB;
-                const float* xb = inb + (size_t)tb * kB;
-                zb[14] = mk(xa[ft], xb[ft]);
-                zb[15] = mk(xa[ft + kThreads], xb[ft + kThreads]);
+            const size_t ca = (size_t)(2 * q) * kB, cb_ = ca + kB;
+            const float* const cur = in + nb * step;
+            z[14] = mk(cur[ca + ft], cur[cb_ + ft]);
+            z[15] = mk(cur[ca + ft + kThreads], cur[cb_ + ft + kThreads]);
+            if (nb > 0) {                                             // block k-1 = the previous input buffer
+                const float* const prv = cur - step;
+                z[12] = mk(prv[ca + ft], prv[cb_ + ft]);
+                z[13] = mk(prv[ca + ft + kThreads], prv[cb_ + ft + kThreads]);
+            } else {
+                const int s = ((head + kSlots - 1) & (kSlots - 1)) * kB;
+                z[12] = hp[s + ft];
+                z[13] = hp[s + kThreads + ft];
             }
 #pragma unroll
-            for (int r = 0; r < 14; ++r)                              // blocks k-7 .. k-1, oldest first
-                zb[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
-            __builtin_amdgcn_sched_barrier(0);
-            float4 cb[16];
-            load_spectra<kNB, 16>(cb, sp.pmF + (size_t)q * kBinsB, ft);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 12; ++r)                              // blocks k-7 .. k-2
+                z[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
+            load_spectra<kNB, 16>(c, sp.pmF + (size_t)q * kBinsB, ft);
+        };
+        cf zb[16], zn[16];                                            // zn: partner values, then the next window
+        float4 cb[16];
+        load_window(0, zb, cb);
+        for (int nb = 0; nb < n_buffers; ++nb) {
+            const int head = (head0 + nb) & (kSlots - 1);
+            const int q = 2 * d + (head & 1);
+            cf* const cp = sp.carry + (size_t)q * kCarrySlots * kB;
             FB::run(zb, X, Y, twb, ft);                               // 2 barriers
-            cf zpb[16];
-            partner_exchange<kNB, 16, true>(zb, zpb, X, ft);          // 1 barrier
-            spectral_product<kNB, 16>(zb, zpb, cb, ft);
-            FBi::template run<typename FB::Twiddles, 4>(zb, Y, X, twb, ft);     // 2 barriers; only [12..15]
+            partner_exchange<kNB, 16, true>(zb, zn, X, ft);           // 1 barrier
+            spectral_product<kNB, 16>(zb, zn, cb, ft);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nb + 1 < n_buffers) load_window(nb + 1, zn, cb);      // flies under the inverse transform
+            __builtin_amdgcn_sched_barrier(0);
+            FBi::template run<typename FB::Mixed, 4>(zb, Y, X, twb, ft);     // 2 barriers; only [12..15]
             cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;          // block k+1
             cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;          // block k+2
             c1[ft] = zb[12];
@@ -703,6 +720,8 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
             c2[ft] = zb[14];
             c2[ft + kThreads] = zb[15];
             __syncthreads();                                          // closes the buffer
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zb[r] = zn[r];
         }
         return;
     }
@@ -721,30 +740,31 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
     WF::load_twiddles(t, tw, lane);
     const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
     const float4* const pm = (second ? sp.pmA2 : pmA) + (size_t)q * kBinsA;
+    // a block of this pair as complex (channel a, channel b): from input buffer nb - back when that
+    // lies inside the launch, from the ring otherwise
+    auto load_block = [&](int nb, int back, cf* z8) {
+        if (nb - back >= 0) {
+            const float* const xa = in + (nb - back) * step + (size_t)ta * kB;
+            const float* const xb = xa + kB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z8[j] = mk(xa[lane + 64 * j], xb[lane + 64 * j]);
+        } else {
+            const int s = ((head0 + nb - back) & (kSlots - 1)) * kB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z8[j] = hp[s + lane + 64 * j];
+        }
+    };
+    auto load_window = [&](int nb, cf (&z)[16]) {                     // A: [k-1 | k]; A2: [k-2 | k-1]
+        load_block(nb, second ? 2 : 1, &z[0]);
+        load_block(nb, second ? 1 : 0, &z[8]);
+    };
+    cf z[16], zn[16];                                                 // zn: partner values, then the next window
+    load_window(0, z);
     for (int nb = 0; nb < n_buffers; ++nb) {
         const int head = (head0 + nb) & (kSlots - 1);
-        const float* const inb = in + nb * step;
         float* const outb = out + nb * step;
-        const int s1 = ((head + kSlots - 1) & (kSlots - 1)) * kB;     // block k-1
-        const int s2 = ((head + kSlots - 2) & (kSlots - 1)) * kB;     // block k-2
-        cf z[16];
-        if (!second) {
-            const float* xa = inb + (size_t)ta * kB;
-            const float* xb = inb + (size_t)tb * kB;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[8 + j] = mk(xa[lane + 64 * j], xb[lane + 64 * j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = hp[s1 + lane + 64 * j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[8 + j] = hp[s1 + lane + 64 * j];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float4 c[16];
+        float4 c[16];                                                 // spectra: not needed before the product
         load_spectra<kNA, 16>(c, pm, lane);
-        __builtin_amdgcn_sched_barrier(0);
         if (!second) {                                                // the new block enters the ring
 #pragma unroll
             for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = z[8 + j];
@@ -752,20 +772,20 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
         __syncthreads();                                              // (1) beside the far role's first pass
         WF::run(z, img, t, lane);
         __syncthreads();                                              // (2) beside its second pass
-        {
-            cf zp[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
-            __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
-            spectral_product<kNA, 16>(z, zp, c, lane);
-        }
+        for (int r = 0; r < 16; ++r) zn[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+        spectral_product<kNA, 16>(z, zn, c, lane);
         __builtin_amdgcn_wave_barrier();
         if (second) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nb + 1 < n_buffers) load_window(nb + 1, zn);              // flies under the inverse transform
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                              // (3) the A2 products are in LDS
         cf y[8];
         if (!second) {
@@ -810,6 +830,8 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
             }
         }
         __syncthreads();                                              // closes the buffer
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = zn[r];
     }
 }
 
