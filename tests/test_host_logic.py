@@ -145,3 +145,25 @@ def test_dawsim_jitter_is_bounded_and_rejects_bad_arguments():
         gab.harness.DawSim(buffer_seconds=0.0)
     with pytest.raises(gab.GabError):
         gab.harness.DawSim(buffer_seconds=0.01, jitter_us=-1.0)
+
+
+def test_trace_period_tool_on_a_synthetic_trace(tmp_path):
+    """tools/trace_period.py: the per-buffer period and the kernels-in-flight figure from a
+    rocprofv3 kernel-trace CSV — two range kernels per buffer, overlapping on two streams."""
+    import csv, json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = tmp_path / "t_kernel_trace.csv"
+    with open(f, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        for k in range(100):                              # buffer k: two 7 us kernels, 8 us period, offset by 3 us
+            for r in range(2):
+                t0 = 1000000 + 8000 * k + 3000 * r
+                w.writerow(["KERNEL_DISPATCH", "gab::(anonymous namespace)::conv_split_range_kernel(float const*)", t0, t0 + 7000])
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_period.py"), str(f), "--kernel", "conv_split_range",
+                          "--last", "200", "--per-buffer", "2"], capture_output=True, text=True, check=True).stdout
+    d = json.loads(out)
+    assert d["kernel"] == "conv_split_range_kernel" and d["launches_per_buffer"] == 2 and d["buffers"] == 100
+    assert abs(d["avg_kernel_duration_us"] - 7.0) < 1e-9
+    assert abs(d["period_us_per_buffer"] - (8000 * 99 + 3000 + 7000) / 100 / 1e3) < 1e-9
+    assert 1.7 < d["avg_kernels_in_flight"] < 1.76
