@@ -835,13 +835,6 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
     }
 }
 
-// Occupies one wave for about `ticks` of the 100 MHz real-time counter: offsets the phase of a chain
-// of launches against the chains on other streams (gab_conv_stream_ranges).
-__global__ void conv_phase_delay_kernel(unsigned ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
 // IR bank -> (P, M) spectra of a near (512 taps from offA) and a far (taps from offB) partition.
 // d_ir is T x L track-major.
 __global__ __launch_bounds__(kThreads) void conv_ir_spectra_kernel(
@@ -1492,16 +1485,12 @@ int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in,
         for (int r = 0; r < n_ranges; ++r) p->order_after_reset(gab::as_stream(streams[r]));
         p->fresh = false;
         const int head0 = p->head;
-        static const int phase_ticks = getenv("GAB_CONV_PHASE_TICKS") ? atoi(getenv("GAB_CONV_PHASE_TICKS")) : 0;
-        static const int swap_odd = getenv("GAB_CONV_RANGE_SWAP") ? atoi(getenv("GAB_CONV_RANGE_SWAP")) : 0;
         auto chain = [&](int r) -> int {
             hipStream_t s = gab::as_stream(streams[r]);
             static const int dbg = getenv("GAB_CONV_SPLIT_DEBUG") ? atoi(getenv("GAB_CONV_SPLIT_DEBUG")) : 0;
             // diagnostic builds: stamp rows of a range start at its first workgroup (first_channel / 2)
             static const int stamp_at = getenv("GAB_CONV_STAMP_AT") ? atoi(getenv("GAB_CONV_STAMP_AT")) : -1;
-            const int flags0 = ((swap_odd && (r & 1)) ? 256 : 0) | (dbg & 0xfffff) | ((first_channel[r] / 2) << 20);
-            if (r > 0 && phase_ticks > 0)
-                gab::conv_phase_delay_kernel<<<1, 64, 0, s>>>((unsigned)(phase_ticks * r));
+            const int flags0 = (dbg & 0xfffff) | ((first_channel[r] / 2) << 20);
             for (int i = 0; i < n_buffers; ++i) {
                 // GAB_CONV_STAMP_AT=i (diagnostic builds): only buffers i and i+1 of the call are stamped
                 const int flags = (stamp_at < 0 || i == stamp_at || i == stamp_at + 1) ? flags0 : (flags0 & ~(64 | 128));
