@@ -94,9 +94,6 @@ PROTOTYPES = {
     "gab_conv_set_ir": (_I, [_P, _P, _P]),
     "gab_conv_reset": (_I, [_P, _P]),
     "gab_conv_process": (_I, [_P, _P, _P, _I, _P]),
-    "gab_conv_process_range": (_I, [_P, _P, _P, _I, _I, _P]),
-    "gab_conv_advance": (_I, [_P]),
-    "gab_conv_stream_ranges": (_I, [_P, C.POINTER(_P), _I, _P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_P), _I, _I]),
     "gab_conv_set_scheme": (_I, [_P, _I]),
     "gab_conv_get_scheme": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_process_batch": (_I, [_P, _P, _P, _I, _P]),

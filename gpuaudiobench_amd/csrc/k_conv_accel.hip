@@ -145,30 +145,12 @@ __device__ __forceinline__ void spectral_product(cf (&z)[R], const cf (&zraw)[R]
     }
 }
 
-// Diagnostic builds (-DGAB_ABLATE) can stamp phase boundaries; see tools/stamp_conv.py.
 template <typename T>
 __device__ __forceinline__ void keep_alive(const T& v) {
     const float* f = reinterpret_cast<const float*>(&v);
 #pragma unroll
     for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("" ::"v"(f[i]));
 }
-
-#ifdef GAB_ABLATE
-// ABL == 6: lane 0 of every workgroup records s_memrealtime (100 MHz) at phase
-// boundaries into a buffer nothing else reads.
-__device__ unsigned long long g_conv_stamps[8 * 4096];
-#define GAB_STAMP_T(i, t)                                                              \
-    do {                                                                               \
-        if constexpr (ABL == 6 || ABL == 7) {                                          \
-            __builtin_amdgcn_sched_barrier(0);                                         \
-            if (threadIdx.x == (t)) g_conv_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-            __builtin_amdgcn_sched_barrier(0);                                         \
-        }                                                                              \
-    } while (0)
-#else
-#define GAB_STAMP_T(i, t) do {} while (0)
-#endif
-#define GAB_STAMP(i) GAB_STAMP_T(i, 0)
 
 #ifdef GAB_ABLATE
 // split kernel (debug bit 64): [launch parity][block][8] of s_memrealtime; slot 6 = HW_ID, 7 = XCC_ID.
@@ -196,7 +178,7 @@ __device__ unsigned long long g_split_stamps[2 * 8 * 8192];
 // the transforms are bound by LDS write bandwidth and VALU throughput, not by the
 // per-thread instruction chain, and radix-8 needs a third exchange.)
 // One buffer of one channel pair; the body of the kernels below.
-template <bool STREAM, bool TAIL, int ABL>
+template <bool STREAM, bool TAIL>
 __device__ __forceinline__ void conv_one_buffer(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
@@ -216,7 +198,6 @@ __device__ __forceinline__ void conv_one_buffer(
     using FB = fft::BlockFFT<kNB, 16, false>;
     using FBi = fft::BlockFFT<kNB, 16, true>;
 
-    GAB_STAMP(0);
     cf zb[16];
     cf za[4];
     float4 ca[4];
@@ -262,15 +243,6 @@ __device__ __forceinline__ void conv_one_buffer(
         hp[head * kB + tid] = za[2];
         hp[head * kB + kThreads + tid] = za[3];
     }
-    GAB_STAMP(1);
-#ifdef GAB_ABLATE
-    if constexpr (ABL == 6) {
-        if (threadIdx.x == 0) {
-            g_conv_stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
-            g_conv_stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
-        }
-    }
-#endif
     // Two of these workgroups share a CU and the one dispatched second (blockIdx + grid/2
     // on a 512-workgroup grid) gets its first data ~1 us later and then loses most issue
     // arbitration to the older waves: it finished 2.6 us after its neighbour.  Raising its
@@ -312,31 +284,8 @@ __device__ __forceinline__ void conv_one_buffer(
             ya1 += zb[15].x; yb1 += zb[15].y;
         }
     };
-#ifdef GAB_ABLATE
-    if constexpr (ABL == 7) {
-        // I-cache experiment: the same code three times; slots 2,3,4 = A done x3, then B x2 in 5,6
-        for (int i = 0; i < 3; ++i) {
-            part_a(lds0, lds1);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            if (threadIdx.x == 0) g_conv_stamps[blockIdx.x * 8 + 2 + i] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        for (int i = 0; i < 2; ++i) {
-            part_b(lds1, lds0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            if (threadIdx.x == 0) g_conv_stamps[blockIdx.x * 8 + 5 + i] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else
-#endif
-    {
     part_a(lds0, lds1);
-    GAB_STAMP(2);
     part_b(lds1, lds0);
-    GAB_STAMP(6);
-    }
 
     // ---- scatter: sample-major out[T*s + t], s = tid and tid+256 -----------
     float* o0 = out + (size_t)T * tid + ta;
@@ -349,16 +298,15 @@ __device__ __forceinline__ void conv_one_buffer(
         o1[0] = ya1;
         if (hasb) { o0[1] = yb0; o1[1] = yb1; }
     }
-    GAB_STAMP(7);
 }
 
-template <bool STREAM, bool TAIL, int ABL = 0>
+template <bool STREAM, bool TAIL>
 __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
     const cf* __restrict__ tw, int T, int head) {
     __shared__ cf lds[2 * kLdsHalf];
-    conv_one_buffer<STREAM, TAIL, ABL>(in, out, hist, pmA, pmB, tw, T, head, lds);
+    conv_one_buffer<STREAM, TAIL>(in, out, hist, pmA, pmB, tw, T, head, lds);
 }
 
 // ---- split roles: near and far partitions on different workgroups ---------------------------
@@ -382,8 +330,18 @@ struct ConvSplit {
     const float4* pmA2;    // [pairs][kBinsA]   taps [512,1024)
     const float4* pmF;     // [pairs][kBinsB]   taps [1024,4096)
     cf* carry;             // [pairs][4][512]   F's outputs, slot = block & 3
-    int debug;             // timing experiments (GAB_CONV_SPLIT_DEBUG): 1 near workgroups exit, 4 far workgroups exit
+#ifdef GAB_ABLATE
+    int debug;             // diagnostic builds only (GAB_CONV_SPLIT_DEBUG): role / stage ablations, stamps
+#endif
 };
+
+// Stage ablations exist in diagnostic builds only (-DGAB_ABLATE, libgab_hip_ablate.so): the product
+// kernels have no path that skips work.
+#ifdef GAB_ABLATE
+#define GAB_SDBG(bit) ((sp.debug & (bit)) != 0)
+#else
+#define GAB_SDBG(bit) false
+#endif
 
 constexpr int kCarrySlots = 4;
 using PadA16 = fft::Pad<16>;
@@ -404,24 +362,24 @@ __device__ __forceinline__ void conv_split_buffer(
     int slot;                                                         // index within the role
     if ((gridDim.x & 511) == 0) {
         const int run = blockIdx.x >> 8;
-        far = ((run & 1) != 0) != ((sp.debug & 256) != 0);           // debug 256: far workgroups first
+        far = ((run & 1) != 0) != GAB_SDBG(256);                      // diagnostic bit 256: far workgroups first
         slot = (run >> 1) * 256 + (blockIdx.x & 255);
     } else {
-        far = ((int)blockIdx.x >= duos) != ((sp.debug & 256) != 0);
+        far = ((int)blockIdx.x >= duos) != GAB_SDBG(256);
         slot = (int)blockIdx.x >= duos ? blockIdx.x - duos : blockIdx.x;
     }
     const int d = xcd_contiguous(slot, duos);
 
     GAB_SSTAMP(0);
 #ifdef GAB_ABLATE
-    if ((sp.debug & 64) && threadIdx.x == 0) {
+    if (GAB_SDBG(64) && threadIdx.x == 0) {
         g_split_stamps[((head & 1) * 8192 + (sp.debug >> 20) + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
         g_split_stamps[((head & 1) * 8192 + (sp.debug >> 20) + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
     }
 #endif
     if (far) {
-        if (sp.debug & 4) return;
-        if (sp.debug & 512) __builtin_amdgcn_s_setprio(2);
+        if (GAB_SDBG(4)) return;
+        if (GAB_SDBG(512)) __builtin_amdgcn_s_setprio(2);
         // ---- F of one pair: window = the seven newest blocks of the ring + the new block
         const int q = 2 * d + (head & 1);
         const int ta = 2 * q, tb = ta + 1;
@@ -462,7 +420,7 @@ __device__ __forceinline__ void conv_split_buffer(
         GAB_SSTAMP(4);
         cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;            // block k+1
         cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;            // block k+2
-        if (sp.debug & 16) { keep_alive(zb[12]); keep_alive(zb[13]); keep_alive(zb[14]); keep_alive(zb[15]); return; }
+        if (GAB_SDBG(16)) { keep_alive(zb[12]); keep_alive(zb[13]); keep_alive(zb[14]); keep_alive(zb[15]); return; }
         c1[tid] = zb[12];
         c1[tid + kThreads] = zb[13];
         c2[tid] = zb[14];
@@ -471,8 +429,8 @@ __device__ __forceinline__ void conv_split_buffer(
         return;
     }
 
-    if (sp.debug & 1) return;
-    if (sp.debug & 1024) __builtin_amdgcn_s_setprio(2);
+    if (GAB_SDBG(1)) return;
+    if (GAB_SDBG(1024)) __builtin_amdgcn_s_setprio(2);
     // ---- near: wave w holds one 1024-point transform: pair (w >> 1) of the duo, window w & 1
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -508,7 +466,7 @@ __device__ __forceinline__ void conv_split_buffer(
     load_spectra<kNA, 16>(c, (second ? sp.pmA2 : pmA) + (size_t)q * kBinsA, lane);
     __builtin_amdgcn_sched_barrier(0);
     WF::expand_twiddles(t);
-    if (!second && !(sp.debug & 8)) {                                 // the new block enters the ring
+    if (!second && !GAB_SDBG(8)) {                                 // the new block enters the ring
 #pragma unroll
         for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = z[8 + j];
     }
@@ -534,7 +492,7 @@ __device__ __forceinline__ void conv_split_buffer(
     __syncthreads();
     GAB_SSTAMP(3);
     cf y[8];
-    const bool pieces8 = (sp.debug & 2048) != 0;      // A/B: one float2 per pair and sample, no swap
+    const bool pieces8 = GAB_SDBG(2048);      // A/B: one float2 per pair and sample, no swap
     if (pieces8 && second) return;
     if (!second) {
         {
@@ -570,7 +528,7 @@ __device__ __forceinline__ void conv_split_buffer(
     }
     __syncthreads();
     if (second) return;
-    if (sp.debug & 32) {
+    if (GAB_SDBG(32)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) keep_alive(y[j]);
         return;
@@ -604,15 +562,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(
 }
 
 
-// Channel-range launches (gab_conv_process_range) under their own name: they carry a part of a
-// buffer each, and profilers average per kernel name.
-__global__ __launch_bounds__(kThreads, 2) void conv_split_range_kernel(
-    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
-    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head) {
-    __shared__ cf lds[2 * kLdsHalf];
-    conv_split_buffer(in, out, hist, pmA, sp, tw, T, head, lds);
-}
-
 // The same kernel under its own name for buffers that live in pinned host memory (the kernel then
 // moves them over the link itself): such launches run at link speed, and profilers average per
 // kernel name — this keeps them out of the figures of the HBM-resident launches.
@@ -622,7 +571,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_overlap_save_host_io_kernel(
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
     const cf* __restrict__ tw, int T, int head) {
     __shared__ cf lds[2 * kLdsHalf];
-    conv_one_buffer<true, TAIL, 0>(in, out, hist, pmA, pmB, tw, T, head, lds);
+    conv_one_buffer<true, TAIL>(in, out, hist, pmA, pmB, tw, T, head, lds);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalf];
+    conv_split_buffer(in, out, hist, pmA, sp, tw, T, head, lds);
 }
 
 // The launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup walks them
@@ -637,7 +593,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
     __shared__ cf lds[2 * kLdsHalf];
     const size_t step = (size_t)T * kB;
     for (int nb = 0; nb < n_buffers; ++nb)
-        conv_one_buffer<true, true, 0>(in + nb * step, out + nb * step, hist, pmA, pmB, tw, T,
+        conv_one_buffer<true, true>(in + nb * step, out + nb * step, hist, pmA, pmB, tw, T,
                                        (head + nb) & (kSlots - 1), lds);
 }
 
@@ -1104,6 +1060,17 @@ __global__ void conv_direct_shift_kernel(const float* __restrict__ in, const flo
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+#ifdef GAB_ABLATE
+// diagnostic builds: the ablation mask of the split kernels comes from the environment
+static int gab_split_debug_mask() {
+    static const int dbg = getenv("GAB_CONV_SPLIT_DEBUG") ? atoi(getenv("GAB_CONV_SPLIT_DEBUG")) : 0;
+    return dbg;
+}
+#define GAB_SPLIT_DEBUG_ARG , gab_split_debug_mask()
+#else
+#define GAB_SPLIT_DEBUG_ARG
+#endif
+
 struct gab_conv_plan {
     int tracks = 0, bufsize = 0, ir_len = 0;
     int pairs = 0;
@@ -1119,15 +1086,14 @@ struct gab_conv_plan {
     int hlen = 0;
     size_t spectra_bytes = 0, history_bytes = 0;
     const gab::fft::cf* tw = nullptr;
-    // split roles (conv_split_kernel): its spectra and the carry ring.  `split_live`: the carry
-    // ring holds what the next launch expects — true from a reset until something else moves the
-    // history ring.
+    // split roles (conv_split_kernel): its spectra and the carry ring.  A plan keeps ONE cut of the
+    // taps from its first buffer to the next reset: every streaming entry (one buffer, a batch, pinned
+    // host buffers) launches that cut.
     bool split = false;
     float4* pmA2 = nullptr;
     float4* pmF = nullptr;
     gab::fft::cf* carry = nullptr;
     size_t carry_bytes = 0;
-    bool split_live = false;
     bool fresh = true;        // nothing has run since the last reset
     // uniform partitions (conv_uniform_kernel): other power-of-two buffer sizes / longer responses
     bool uniform = false;
@@ -1198,16 +1164,14 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
                 p->history_bytes = sizeof(float) * (size_t)p->pairs * 2 * gab::kSlots * gab::kB;
                 GAB_HIP_CHECK(hipMalloc(&p->hist, p->history_bytes));
                 GAB_HIP_CHECK(hipMemset(p->hist, 0, p->history_bytes));
-                const char* scheme = getenv("GAB_CONV_SCHEME");
                 const bool can_split = ir_len > 2 * gab::kB && (tracks % 4) == 0;
-                p->split = can_split && !(scheme && std::string(scheme) == "classic");
+                p->split = can_split;                  // gab_conv_set_scheme picks the classic cut
                 if (can_split) {
                     GAB_HIP_CHECK(hipMalloc(&p->pmA2, a));
                     GAB_HIP_CHECK(hipMalloc(&p->pmF, b));
                     p->carry_bytes = sizeof(gab::fft::cf) * (size_t)p->pairs * gab::kCarrySlots * gab::kB;
                     GAB_HIP_CHECK(hipMalloc(&p->carry, p->carry_bytes));
                     GAB_HIP_CHECK(hipMemset(p->carry, 0, p->carry_bytes));
-                    p->split_live = p->split;
                 }
             } else {
                 int blocks = (ir_len - 1 + bufsize - 1) / bufsize;
@@ -1266,7 +1230,6 @@ int gab_conv_set_ir(gab_conv_plan* p, const float* d_ir, gab_stream_t stream) {
                     d_ir, p->pmA2, p->pmF, p->tw, p->tracks, p->ir_len, gab::kB, 2 * gab::kB);
             int rc = gab::launch_status("conv_ir_spectra_kernel");
             if (rc) return rc;
-            if (!p->fresh) p->split_live = false;    // parked far shares were made with the old taps
         } else {
             GAB_HIP_CHECK(hipMemcpyAsync(p->ir_copy, d_ir, p->spectra_bytes,
                                          hipMemcpyDeviceToDevice, s));
@@ -1284,17 +1247,13 @@ int gab_conv_set_scheme(gab_conv_plan* p, int scheme) {
     if (!p->fresh) return gab::bad_arg("gab_conv_set_scheme: only on a fresh plan (before the first buffer or right after a reset)");
     if (scheme == GAB_CONV_SCHEME_SPLIT && !p->pmF)
         return gab::bad_arg("gab_conv_set_scheme: the split scheme needs 512-sample buffers, 1025..4096 taps and a channel count divisible by 4");
-    const bool want = scheme == GAB_CONV_SCHEME_SPLIT;
-    p->split = want;
-    p->split_live = want;
+    p->split = scheme == GAB_CONV_SCHEME_SPLIT;
     return GAB_OK;
 }
 
 int gab_conv_get_scheme(const gab_conv_plan* p, int* scheme) {
     if (!p || !scheme) return gab::bad_arg("gab_conv_get_scheme: null pointer");
-    // what the NEXT streaming launch will use: a split plan that a batch, host-io or set_ir call has
-    // moved on without the carry ring runs classic launches until its next reset
-    *scheme = (p->split && p->split_live) ? GAB_CONV_SCHEME_SPLIT : GAB_CONV_SCHEME_CLASSIC;
+    *scheme = p->split ? GAB_CONV_SCHEME_SPLIT : GAB_CONV_SCHEME_CLASSIC;
     return GAB_OK;
 }
 
@@ -1324,7 +1283,6 @@ int gab_conv_reset(gab_conv_plan* p, gab_stream_t stream) {
             p->reset_stream = s;
             p->reset_recorded = true;
         }
-        p->split_live = p->split;
         p->fresh = true;
         return GAB_OK;
     });
@@ -1358,19 +1316,21 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
             dim3 grid(p->pairs), block(gab::kThreads);
 #define GAB_CONV_ARGS d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head
             if (streaming) p->fresh = false;
-            // (host-io launches keep the classic cut: with the split one the new block would cross
-            // the link twice, once for each role — 99 us against 90 us per round trip)
-            if (mode == GAB_CONV_STREAMING && p->split && p->split_live) {
-                static const int dbg = getenv("GAB_CONV_SPLIT_DEBUG") ? atoi(getenv("GAB_CONV_SPLIT_DEBUG")) : 0;
-                gab::ConvSplit sp{p->pmA2, p->pmF, p->carry, dbg};
-                gab::conv_split_kernel<<<grid, block, 0, s>>>(d_in, d_out, p->hist, p->pmA, sp, p->tw,
-                                                             p->tracks, p->head);
+            if (streaming && p->split) {
+                // pinned host buffers: the same kernel under its own name (it runs at link speed: the new
+                // block crosses the link once per role, 99 us per round trip against the classic cut's 90)
+                gab::ConvSplit sp{p->pmA2, p->pmF, p->carry GAB_SPLIT_DEBUG_ARG};
+                if (mode == GAB_CONV_STREAMING_HOST_IO)
+                    gab::conv_split_host_io_kernel<<<grid, block, 0, s>>>(d_in, d_out, p->hist, p->pmA, sp, p->tw,
+                                                                         p->tracks, p->head);
+                else
+                    gab::conv_split_kernel<<<grid, block, 0, s>>>(d_in, d_out, p->hist, p->pmA, sp, p->tw,
+                                                                 p->tracks, p->head);
                 int rc = gab::launch_status("conv_split_kernel");
                 if (rc) return rc;
                 p->head = (p->head + 1) & (gab::kSlots - 1);
                 return GAB_OK;
             }
-            if (streaming) p->split_live = false;     // the history ring moves on without the carry ring
             if (mode == GAB_CONV_STREAMING_HOST_IO) {
                 if (p->tail) gab::conv_overlap_save_host_io_kernel<true><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
                 else gab::conv_overlap_save_host_io_kernel<false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
@@ -1378,12 +1338,6 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
                 gab::conv_overlap_save_kernel<false, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
             else if (!p->tail)
                 gab::conv_overlap_save_kernel<true, false><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
-#ifdef GAB_ABLATE
-            else if (getenv("GAB_CONV_ABLATE") && atoi(getenv("GAB_CONV_ABLATE")) == 6)
-                gab::conv_overlap_save_kernel<true, true, 6><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
-            else if (getenv("GAB_CONV_ABLATE") && atoi(getenv("GAB_CONV_ABLATE")) == 7)
-                gab::conv_overlap_save_kernel<true, true, 7><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
-#endif
             else
                 gab::conv_overlap_save_kernel<true, true><<<grid, block, 0, s>>>(GAB_CONV_ARGS);
 #undef GAB_CONV_ARGS
@@ -1410,144 +1364,6 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
     });
 }
 
-// One buffer, a RANGE of the channels: the same launch as gab_conv_process on offset base pointers
-// (every per-channel array is laid out by channel pair; the output keeps the plan's full stride).
-// Channels are independent, so a caller may give disjoint ranges to different streams: each stream
-// is then its own chain of dependent launches, and the chains overlap each other's kernel
-// boundaries.  The ring position is the plan's: call gab_conv_advance once per buffer, after every
-// range of that buffer has been queued.
-}  // extern "C"
-
-namespace {
-
-int check_range(const gab_conv_plan* p, const char* who, int first_channel, int n_channels) {
-    if (!(p->split && p->split_live))
-        return gab::bad_arg((std::string(who) + ": needs a plan on the split cut (see gab_conv_set_scheme)").c_str());
-    if (first_channel < 0 || n_channels <= 0 || (first_channel & 3) || (n_channels & 3) ||
-        first_channel + n_channels > p->tracks)
-        return gab::bad_arg((std::string(who) + ": the range must lie inside the plan and start and end on multiples of 4 channels").c_str());
-    return GAB_OK;
-}
-
-// the launch itself; `head` is the ring slot of this buffer
-int launch_range(gab_conv_plan* p, const float* d_in, float* d_out, int first_channel, int n_channels,
-                 int head, hipStream_t s, int flags = 0) {
-    const size_t q0 = (size_t)first_channel / 2;
-    gab::ConvSplit sp{p->pmA2 + q0 * gab::kBinsA, p->pmF + q0 * gab::kBinsB,
-                      p->carry + q0 * gab::kCarrySlots * gab::kB, flags};
-    gab::conv_split_range_kernel<<<dim3(n_channels / 2), dim3(gab::kThreads), 0, s>>>(
-        d_in + (size_t)first_channel * p->bufsize, d_out + first_channel,
-        p->hist + q0 * 2 * gab::kSlots * gab::kB, p->pmA + q0 * gab::kBinsA, sp, p->tw, p->tracks, head);
-    return gab::launch_status("conv_split_range_kernel");
-}
-
-}  // namespace
-
-extern "C" {
-
-int gab_conv_process_range(gab_conv_plan* p, const float* d_in, float* d_out, int first_channel,
-                           int n_channels, gab_stream_t stream) {
-    return gab::guarded([&]() -> int {
-        if (!p || !d_in || !d_out) return gab::bad_arg("gab_conv_process_range: null argument");
-        if (!p->ir_set) return gab::bad_arg("gab_conv_process_range: gab_conv_set_ir has not been called");
-        int rc = check_range(p, "gab_conv_process_range", first_channel, n_channels);
-        if (rc) return rc;
-        hipStream_t s = gab::as_stream(stream);
-        p->order_after_reset(s);
-        p->fresh = false;
-        return launch_range(p, d_in, d_out, first_channel, n_channels, p->head, s);
-    });
-}
-
-// n_buffers consecutive buffers (input i = d_in[i % n_in]), each queued as n_ranges channel ranges
-// on their streams: the loop a native host would write around gab_conv_process_range /
-// gab_conv_advance.  With more than one range every range gets its own host thread for the
-// duration of the call: a launch costs the host 3-4 us, so ONE thread feeding R streams cannot
-// queue faster than R x that per buffer, which is slower than the device runs them.
-int gab_conv_stream_ranges(gab_conv_plan* p, const float* const* d_in, int n_in, float* d_out,
-                           const int* first_channel, const int* n_channels, const gab_stream_t* streams,
-                           int n_ranges, int n_buffers) {
-    return gab::guarded([&]() -> int {
-        if (!p || !d_in || !d_out || !first_channel || !n_channels || !streams)
-            return gab::bad_arg("gab_conv_stream_ranges: null argument");
-        if (n_in <= 0 || n_ranges <= 0 || n_buffers < 0) return gab::bad_arg("gab_conv_stream_ranges: counts must be positive");
-        if (!p->ir_set) return gab::bad_arg("gab_conv_stream_ranges: gab_conv_set_ir has not been called");
-        for (int r = 0; r < n_ranges; ++r) {
-            int rc = check_range(p, "gab_conv_stream_ranges", first_channel[r], n_channels[r]);
-            if (rc) return rc;
-            for (int q = 0; q < r; ++q)
-                if (first_channel[r] < first_channel[q] + n_channels[q] && first_channel[q] < first_channel[r] + n_channels[r])
-                    return gab::bad_arg("gab_conv_stream_ranges: ranges overlap");
-        }
-        for (int i = 0; i < n_in; ++i)
-            if (!d_in[i]) return gab::bad_arg("gab_conv_stream_ranges: null input buffer");
-        if (n_buffers == 0) return GAB_OK;
-        for (int r = 0; r < n_ranges; ++r) p->order_after_reset(gab::as_stream(streams[r]));
-        p->fresh = false;
-        const int head0 = p->head;
-        auto chain = [&](int r) -> int {
-            hipStream_t s = gab::as_stream(streams[r]);
-            static const int dbg = getenv("GAB_CONV_SPLIT_DEBUG") ? atoi(getenv("GAB_CONV_SPLIT_DEBUG")) : 0;
-            // diagnostic builds: stamp rows of a range start at its first workgroup (first_channel / 2)
-            static const int stamp_at = getenv("GAB_CONV_STAMP_AT") ? atoi(getenv("GAB_CONV_STAMP_AT")) : -1;
-            const int flags0 = (dbg & 0xfffff) | ((first_channel[r] / 2) << 20);
-            for (int i = 0; i < n_buffers; ++i) {
-                // GAB_CONV_STAMP_AT=i (diagnostic builds): only buffers i and i+1 of the call are stamped
-                const int flags = (stamp_at < 0 || i == stamp_at || i == stamp_at + 1) ? flags0 : (flags0 & ~(64 | 128));
-                int rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
-                                      (head0 + i) & (gab::kSlots - 1), s, flags);
-                if (rc) return rc;
-            }
-            return GAB_OK;
-        };
-        static const bool one_thread = getenv("GAB_CONV_RANGE_THREADS") && atoi(getenv("GAB_CONV_RANGE_THREADS")) == 0;
-        int rc = GAB_OK;
-        if (n_ranges == 1) {
-            rc = chain(0);
-        } else if (one_thread) {
-            for (int i = 0; i < n_buffers && !rc; ++i)
-                for (int r = 0; r < n_ranges && !rc; ++r)
-                    rc = launch_range(p, d_in[i % n_in], d_out, first_channel[r], n_channels[r],
-                                      (head0 + i) & (gab::kSlots - 1), gab::as_stream(streams[r]));
-        } else {
-            std::vector<int> rcs(n_ranges, GAB_OK);
-            std::vector<std::string> errs(n_ranges);
-            std::vector<std::thread> workers;
-            workers.reserve(n_ranges);
-            bool spawn_failed = false;
-            for (int r = 1; r < n_ranges && !spawn_failed; ++r) {
-                try {
-                    workers.emplace_back([&, r]() {
-                        if (hipSetDevice(p->device) != hipSuccess) { rcs[r] = GAB_ERR_RUNTIME; errs[r] = "hipSetDevice failed"; return; }
-                        rcs[r] = chain(r);
-                        if (rcs[r]) errs[r] = gab::last_error();      // the error text is thread-local
-                    });
-                } catch (const std::exception& e) {               // no thread to be had: this range is queued from here
-                    spawn_failed = true;
-                    rcs[r] = chain(r);
-                    for (int q = r + 1; q < n_ranges; ++q) rcs[q] = chain(q);
-                }
-            }
-            rcs[0] = chain(0);
-            for (auto& w : workers) w.join();
-            for (int r = 0; r < n_ranges; ++r)
-                if (rcs[r]) {
-                    rc = rcs[r];
-                    if (r) gab::set_last_error(errs[r]);
-                    break;
-                }
-        }
-        p->head = (head0 + n_buffers) & (gab::kSlots - 1);
-        return rc;
-    });
-}
-
-int gab_conv_advance(gab_conv_plan* p) {
-    if (!p) return gab::bad_arg("gab_conv_advance: null plan");
-    p->head = (p->head + 1) & (gab::kSlots - 1);
-    return GAB_OK;
-}
-
 int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, int n_buffers,
                            gab_stream_t stream) {
     return gab::guarded([&]() -> int {
@@ -1555,11 +1371,10 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
         if (!p->ir_set) return gab::bad_arg("gab_conv_process_batch: gab_conv_set_ir has not been called");
         if (n_buffers <= 0) return gab::bad_arg("gab_conv_process_batch: n_buffers must be > 0");
         hipStream_t s = gab::as_stream(stream);
-        if (p->fused && p->split && p->split_live) {
-            // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches,
-            // and the plan stays on the split cut afterwards
+        if (p->fused && p->split) {
+            // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches
             p->order_after_reset(s);
-            gab::ConvSplit sp{p->pmA2, p->pmF, p->carry, 0};
+            gab::ConvSplit sp{p->pmA2, p->pmF, p->carry GAB_SPLIT_DEBUG_ARG};
             gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(2 * gab::kThreads), 0, s>>>(
                 d_in, d_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n_buffers);
             int rc = gab::launch_status("conv_split_batch_kernel");
@@ -1574,7 +1389,6 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
             int rc = gab::launch_status("conv_batch_kernel");
             if (rc) return rc;
             p->head = (p->head + n_buffers) & (gab::kSlots - 1);
-            p->split_live = false;
             p->fresh = false;
             return GAB_OK;
         }
@@ -1599,11 +1413,7 @@ int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* histor
 }
 
 #ifdef GAB_ABLATE
-// diagnostic builds only: copies the phase stamps of the last ABL==6 launch
-int gab_debug_conv_stamps(unsigned long long* h_out, int n) {
-    (void)hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_conv_stamps), sizeof(unsigned long long) * n);
-}
+// diagnostic builds only: copies the phase stamps of the last stamped split launch
 int gab_debug_split_stamps(unsigned long long* h_out, int n) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_split_stamps), sizeof(unsigned long long) * n);

@@ -590,9 +590,11 @@ int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin,
     f->P = P;
     f->z_begin = z_begin;
     f->z_end = z_end;
+#ifdef GAB_ABLATE       // diagnostic builds: pick a kernel form by hand (every form is bit-identical)
     if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
     if (const char* v = getenv("GAB_FDTD_LDS")) f->lds_tiles = atoi(v) != 0;
     if (const char* v = getenv("GAB_FDTD_TILE")) f->sample_tiles = atoi(v) != 0;
+#endif
     const size_t nzl = (size_t)(z_end - z_begin);
     f->np = (size_t)P.nx * P.ny * (nzl + 2);
     f->nvx = (size_t)(P.nx + 4) * P.ny * nzl + 4;    // padded pitch, see file header
@@ -621,7 +623,11 @@ void launch_step(const gab_fdtd_plan* f, hipStream_t q, const gab::Fields& cur, 
     const gab_fdtd_params& P = f->P;
     const int nzl = f->z_end - f->z_begin;
     gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, f->z_begin};
+#ifdef GAB_ABLATE
     static const int stagger_env = getenv("GAB_FDTD_STAGGER") ? atoi(getenv("GAB_FDTD_STAGGER")) : -1;
+#else
+    constexpr int stagger_env = -1;
+#endif
     const size_t sxy = (size_t)P.nx * P.ny;
     const size_t src = P.source_z * sxy + (size_t)P.source_y * P.nx + P.source_x;
     const size_t rcv = P.receiver_z * sxy + (size_t)P.receiver_y * P.nx + P.receiver_x;

@@ -181,32 +181,15 @@ class ConvPlan:
         check(lib.gab_conv_process_batch(self._h, _dev(x), _dev(out), n_buffers, _stream()))
         return out
 
-    def process_range(self, x, out, first_channel, n_channels, stream=None):
-        """gab_conv_process_range: one buffer, channels [first, first + n) only; x / out are the
-        whole buffers.  Call advance() once per buffer after all its ranges are queued."""
+    def prepare_batch(self, x, n_buffers, out, stream=None):
+        """The ctypes arguments of process_batch(), built once for a loop over the same resident batch."""
+        assert x.numel() == n_buffers * self.tracks * self.bufsize == out.numel()
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
-        check(lib.gab_conv_process_range(self._h, _dev(x), _dev(out), first_channel, n_channels, st))
-
-    def prepare_range(self, x, out, first_channel, n_channels, stream):
-        return (self._h, _dev(x), _dev(out), first_channel, n_channels, C.c_void_p(stream.cuda_stream))
+        return (self._h, _dev(x), _dev(out), n_buffers, st)
 
     @staticmethod
-    def launch_range(args):
-        check(lib.gab_conv_process_range(*args))
-
-    def advance(self):
-        check(lib.gab_conv_advance(self._h))
-
-    def stream_ranges(self, inputs, out, ranges, streams, n_buffers):
-        """gab_conv_stream_ranges: n_buffers consecutive buffers (cycling through `inputs`), each
-        queued as the channel ranges [(first, count), ...] on the matching torch streams."""
-        n = len(ranges)
-        assert len(streams) == n
-        ins = (C.c_void_p * len(inputs))(*[_dev(t).value for t in inputs])
-        first = (C.c_int * n)(*[r[0] for r in ranges])
-        count = (C.c_int * n)(*[r[1] for r in ranges])
-        sts = (C.c_void_p * n)(*[s.cuda_stream for s in streams])
-        check(lib.gab_conv_stream_ranges(self._h, ins, len(inputs), _dev(out), first, count, sts, n, n_buffers))
+    def launch_batch(args):
+        check(lib.gab_conv_process_batch(*args))
 
     def prepare(self, x, out, mode=CONV_STREAMING, stream=None):
         """The ctypes arguments of process(), built once for a loop that cycles through a fixed set

@@ -138,42 +138,22 @@ typedef struct gab_conv_plan gab_conv_plan;
 
 #define GAB_CONV_STATELESS 0  /* reference semantics: zero history each call  */
 #define GAB_CONV_STREAMING 1  /* overlap-save with carried history            */
-/* How a streaming plan cuts the taps (gab_conv_set_scheme; default SPLIT where the shape allows:
- * 512-sample buffers, 1025..4096 taps, channel count divisible by 4; GAB_CONV_SCHEME=classic in
- * the environment makes CLASSIC the default):
+/* How a streaming plan cuts the taps.  Default SPLIT where the shape allows (512-sample buffers,
+ * 1025..4096 taps, channel count divisible by 4), else CLASSIC; gab_conv_set_scheme changes it on a
+ * fresh plan (before the first buffer or right after a reset).  A plan keeps its cut until then:
+ * gab_conv_process (device or pinned host buffers) and gab_conv_process_batch all launch that cut.
  *   CLASSIC  taps [0,512) + [512,4096), both transforms in one workgroup per channel pair;
  *   SPLIT    taps [0,512) + [512,1024) + [1024,4096): the far partition runs for a pair every
- *            other buffer, one buffer ahead, on its own workgroups (conv_split_kernel).  Same
- *            convolution, different rounding: results agree to ~1e-7 of the peak, not bit for bit.
- * Host-io launches always use the CLASSIC cut; after one a SPLIT plan continues with CLASSIC
- * launches until the next gab_conv_reset, and gab_conv_get_scheme reports CLASSIC meanwhile (it
- * answers for the NEXT streaming launch).  gab_conv_process_batch uses the plan's current cut.
+ *            other buffer, one buffer ahead.  Same convolution, different rounding: results agree
+ *            to ~1e-7 of the peak, not bit for bit.
  * Other power-of-two buffer sizes (32..2048) and responses up to 16384 taps run the fused
- * uniform-partition kernel (one cut, no choice); anything else the direct-form last resort.      */
+ * uniform-partition kernel (one cut, no choice); anything else the direct-form last resort.
+ * gab_conv_set_ir on a plan that is mid-stream takes effect with the next buffer; on the SPLIT cut
+ * the far shares already parked for the next two buffers were made with the previous taps.       */
 #define GAB_CONV_SCHEME_CLASSIC 0
 #define GAB_CONV_SCHEME_SPLIT 1
-/* One buffer, a range of the channels (split cut only; first_channel and n_channels multiples of
- * 4): the same launch on offset base pointers; d_in / d_out are the whole buffers.  Disjoint ranges
- * may go to different streams — channels are independent, so each stream is its own chain of
- * launches and the chains overlap each other's kernel boundaries.  gab_conv_advance moves the
- * plan's ring position: once per buffer, after all its ranges have been queued.
- * Ordering: consecutive buffers of a channel range must be ordered by the caller (the same stream
- * for that range every buffer, or events) — the library only orders gab_conv_reset against launches
- * on other streams (it records / waits events itself; no host synchronisation is needed around a
- * reset).  Launch errors are reported by the call that queued the launch.                          */
-int gab_conv_process_range(gab_conv_plan* plan, const float* d_in, float* d_out, int first_channel,
-                           int n_channels, gab_stream_t stream);
-int gab_conv_advance(gab_conv_plan* plan);
-/* The loop around the two calls above, for n_buffers consecutive buffers (input i = d_in[i % n_in],
- * all into d_out): range r of every buffer goes to streams[r].  With more than one range every range
- * gets its own host thread for the duration of the call (a launch costs the host 3-4 us; one thread
- * cannot feed two streams at the rate the device runs them).  Ranges must not overlap.  Returns
- * when everything is QUEUED; the streams are the caller's to synchronise.                         */
-int gab_conv_stream_ranges(gab_conv_plan* plan, const float* const* d_in, int n_in, float* d_out,
-                           const int* first_channel, const int* n_channels, const gab_stream_t* streams,
-                           int n_ranges, int n_buffers);
-int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);   /* fresh plans only (before the first buffer / after reset) */
-int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);   /* the cut the next streaming launch will use */
+int gab_conv_set_scheme(gab_conv_plan* plan, int scheme);
+int gab_conv_get_scheme(const gab_conv_plan* plan, int* scheme);
 #define GAB_CONV_STREAMING_HOST_IO 2  /* the same, d_in / d_out in pinned host memory: identical kernel
                                        * under its own name, so that link-speed launches do not
                                        * mix into per-kernel profiles of the HBM-resident ones    */
@@ -196,8 +176,8 @@ int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
                      int mode, gab_stream_t stream);
 /* n_buffers consecutive buffers in ONE launch (streaming mode): d_in = [n][T*B]
  * track-major buffers back to back, d_out = [n][B*T].  Same results, bit for bit, as n calls of
- * gab_conv_process on the plan's current cut; for callers that have the input ahead of time
- * (offline rendering): no kernel boundary between buffers.  On the split cut a 512-thread
+ * gab_conv_process; for callers whose input is resident ahead of time (offline rendering, and
+ * bench.py's throughput figure): no kernel boundary between buffers.  On the split cut a 512-thread
  * workgroup owns a duo of channel pairs for the whole launch, near role on four waves, far role on
  * the other four (conv_split_batch_kernel).  Additive: the reference processes one buffer per
  * iteration.                                                                     */

@@ -77,3 +77,25 @@ def test_plans_refuse_the_runtime_mode_that_hung():
     assert r.returncode == 0, r.stderr[-1000:]
     rc, text = r.stdout.strip().split(" ", 1)
     assert int(rc) == -3 and "AMD_DIRECT_DISPATCH" in text
+
+
+def test_product_library_has_no_work_skipping_switches():
+    """Stage ablations, stamps and kernel-form overrides (GAB_CONV_SPLIT_DEBUG, GAB_FDTD_*, ...) exist
+    only in diagnostic builds (-DGAB_ABLATE -> libgab_hip_ablate.so): the product library and the
+    driver do not contain the names, so no environment variable can make a product kernel skip work."""
+    blob = open(LIB, "rb").read()
+    driver = os.path.join(ROOT, "gpuaudiobench_amd", "gpubench")
+    if os.path.exists(driver):
+        blob += open(driver, "rb").read()
+    for name in (b"GAB_CONV_SPLIT_DEBUG", b"GAB_CONV_STAMP_AT", b"GAB_CONV_RANGE_THREADS", b"GAB_CONV_ABLATE",
+                 b"GAB_CONV_SCHEME", b"GAB_FDTD_GRAPH", b"GAB_FDTD_LDS", b"GAB_FDTD_TILE", b"GAB_FDTD_STAGGER",
+                 b"g_split_stamps", b"gab_debug_"):
+        assert name not in blob, name
+    # the only environment variable the product reads is the runtime mode it refuses
+    import re
+    src_dir = os.path.join(ROOT, "gpuaudiobench_amd", "csrc")
+    for f in sorted(os.listdir(src_dir)):
+        text = open(os.path.join(src_dir, f), errors="replace").read()
+        text = re.sub(r"#ifdef GAB_ABLATE.*?#endif", "", text, flags=re.S)
+        for var in re.findall(r'getenv\("([A-Z_0-9]+)"\)', text):
+            assert var == "AMD_DIRECT_DISPATCH", (f, var)

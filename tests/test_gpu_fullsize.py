@@ -160,19 +160,20 @@ def test_conv_accel_large_grid_equals_shards(gab, orc):
         p.close()
 
 
-def test_conv_accel_reset_then_ranges_without_host_sync(gab, orc):
-    """gab_conv_reset queues its memsets on the caller's stream; range launches on OTHER streams
-    must still see the cleared rings (the library orders them).  No host synchronisation between
-    the dirtying stream, the reset and the range launches."""
+def test_conv_accel_reset_then_launch_on_another_stream_without_host_sync(gab, orc):
+    """gab_conv_reset queues its memsets on the caller's stream; launches on ANOTHER stream must
+    still see the cleared rings (the library orders them with events).  No host synchronisation
+    between the dirtying stream, the reset and the launches that follow."""
     import torch
     T, B, L = 1024, 512, 4096
     ir = dev(orc.conv_accel_ir(L, T))
     xs = [dev(orc.noise(T * B, seed=3100 + i)) for i in range(4)]
+    xcat = torch.cat(xs[:3])
     a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
     a.set_ir(ir)
     b.set_ir(ir)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    out = torch.empty(T * B, device="cuda")
+    side = torch.cuda.Stream()
+    out = torch.empty(3 * T * B, device="cuda")
     for i in range(3):
         ya = a.process(xs[i], mode=gab.CONV_STREAMING)
     want = host(ya)
@@ -180,9 +181,14 @@ def test_conv_accel_reset_then_ranges_without_host_sync(gab, orc):
         for i in range(9):                              # dirty every ring slot
             b.process(xs[(i + trial) % 4], mode=gab.CONV_STREAMING)
         b.reset()
-        b.stream_ranges(xs, out, [(0, T // 2), (T // 2, T // 2)], [s1, s2], 3)
+        with torch.cuda.stream(side):
+            if trial % 2:
+                b.process_batch(xcat, 3, out=out)
+            else:
+                for i in range(3):
+                    b.process(xs[i], out=out[2 * T * B:], mode=gab.CONV_STREAMING)
         torch.cuda.synchronize()
-        assert np.array_equal(bits(host(out)), bits(want)), trial
+        assert np.array_equal(bits(host(out[2 * T * B:])), bits(want)), trial
     a.close()
     b.close()
 
@@ -250,46 +256,46 @@ def test_fdtd_wide_slab_cut_developed_field(gab, orc):
 
 
 def test_conv_accel_mixed_launch_paths_stay_bit_identical(gab, orc):
-    """A random mix of the ways a streaming buffer can be launched — one launch, two range launches
-    on two streams + advance, the threaded library loop over 1-4 buffers, resets in between, no host
-    synchronisation except where a result is read — walks the same history as a plan that only ever
-    sees gab_conv_process: same bits, every buffer."""
+    """A random mix of the ways a streaming buffer can be launched — one launch, a batch of 1-9
+    buffers, pinned host buffers, on changing streams, resets in between, no host synchronisation
+    except where a result is read — walks the same history as a plan that only ever sees
+    gab_conv_process on device buffers: same bits, every buffer."""
     import torch
     T, B, L = 256, 512, 4096
     ir = dev(orc.conv_accel_ir(L, T))
     ref, mix = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
     ref.set_ir(ir)
     mix.set_ir(ir)
-    xs = [dev(orc.noise(T * B, seed=5000 + i)) for i in range(6)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    hx = [orc.noise(T * B, seed=5000 + i) for i in range(6)]
+    xs = [dev(x) for x in hx]
+    pinned = [torch.from_numpy(x).pin_memory() for x in hx]
+    h_out = torch.empty(T * B).pin_memory()
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
     rng = np.random.default_rng(11)
-    out = torch.empty(T * B, device="cuda")
     n = 0
     for step in range(60):
-        how = int(rng.integers(0, 5))
-        if how == 4 and step > 0:
+        how = int(rng.integers(0, 4))
+        if how == 3 and step > 0:
             ref.reset()
             mix.reset()
             continue
-        count = int(rng.integers(1, 5)) if how == 3 else 1
+        count = int(rng.integers(1, 10)) if how == 1 else 1
         for j in range(count):
             want = ref.process(xs[(n + j) % 6], mode=gab.CONV_STREAMING)
-        if how == 0:
-            mix.process(xs[n % 6], out=out, mode=gab.CONV_STREAMING)
-        elif how in (1, 2):
-            cut = 4 * int(rng.integers(1, T // 4))
-            mix.process_range(xs[n % 6], out, 0, cut, stream=streams[0])
-            mix.process_range(xs[n % 6], out, cut, T - cut, stream=streams[1 + (how == 2)])
-            mix.advance()
-        else:
-            third = 4 * (T // 12)
-            ranges = [(0, third), (third, third), (2 * third, T - 2 * third)]
-            # inputs cycle from index n: rotate the list so that buffer i of the call is xs[(n + i) % 6]
-            rot = [xs[(n + i) % 6] for i in range(6)]
-            mix.stream_ranges(rot, out, ranges, streams, count)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(streams[int(rng.integers(0, 3))]):
+            if how == 0:
+                got = mix.process(xs[n % 6], mode=gab.CONV_STREAMING)
+            elif how == 1:
+                xb = torch.cat([xs[(n + j) % 6] for j in range(count)])
+                got = mix.process_batch(xb, count)[(count - 1) * T * B:]
+            else:
+                mix.process(pinned[n % 6], out=h_out, mode=gab.CONV_STREAMING)
+                got = h_out
         n += count
         torch.cuda.synchronize()
-        assert np.array_equal(bits(host(out)), bits(host(want))), (step, how)
+        assert mix.scheme == "split"
+        assert np.array_equal(bits(got.cpu().numpy()), bits(host(want))), (step, how)
     ref.close()
     mix.close()
 

@@ -325,19 +325,21 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
     T, B, L = 64, 512, 4096
     ir = dev(orc.conv_accel_ir(L, T))
     xs = [orc.noise(T * B, seed=30 + i) for i in range(4)]
-    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L)    # host-io launches use the classic cut
-    a.set_ir(ir)
-    b.set_ir(ir)
     h_out = torch.empty(T * B).pin_memory()
-    for x in xs:
-        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
-        b.process(torch.from_numpy(x).pin_memory(), out=h_out, mode=gab.CONV_STREAMING)
-        torch.cuda.synchronize()
-        assert np.array_equal(bits(ya), bits(h_out.numpy()))
-    with pytest.raises(TypeError):
-        a.process(torch.from_numpy(xs[0]))            # pageable host memory is not device-accessible
-    a.close()
-    b.close()
+    for scheme in ("split", "classic"):               # a host-io launch runs the plan's own cut
+        a, b = gab.ConvPlan(T, B, L, scheme=scheme), gab.ConvPlan(T, B, L, scheme=scheme)
+        a.set_ir(ir)
+        b.set_ir(ir)
+        for x in xs:
+            ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+            b.process(torch.from_numpy(x).pin_memory(), out=h_out, mode=gab.CONV_STREAMING)
+            torch.cuda.synchronize()
+            assert b.scheme == scheme
+            assert np.array_equal(bits(ya), bits(h_out.numpy()))
+        with pytest.raises(TypeError):
+            a.process(torch.from_numpy(xs[0]))        # pageable host memory is not device-accessible
+        a.close()
+        b.close()
 
 
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
@@ -374,9 +376,8 @@ def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
 def test_conv_accel_split_and_classic_streams_agree(gab, orc):
     """The split cut (far partition every other buffer, one buffer ahead, on its own workgroups)
     and the classic cut are the same convolution: 30 buffers agree to rounding, against each other
-    and against the float64 direct form, with a batch call in the middle of both streams; a host-io
-    launch (which moves the history ring without the carry ring) is followed by classic launches
-    that stay correct, and a reset brings the split launches back."""
+    and against the float64 direct form, with a batch call in the middle of both streams and a
+    host-io launch at the end; a plan keeps its cut through all of them."""
     import torch
     T, B, L = 64, 512, 4096
     ir = orc.conv_accel_ir(L, T)
@@ -403,18 +404,18 @@ def test_conv_accel_split_and_classic_streams_agree(gab, orc):
             assert np.abs(yb - ref).max() <= 1e-5 * peak, i
             assert np.abs(ya - yb).max() <= 2e-6 * peak, i
         assert b.scheme == "split"                                # also after the batch call
-    # a host-io launch (pinned buffers) uses the classic cut and leaves the plan on it until a reset
+    # a host-io launch (pinned buffers) runs the plan's own cut
     hx = torch.from_numpy(xs[0]).pin_memory()
     hy = torch.empty(T * B).pin_memory()
     b.process(hx, out=hy, mode=gab.CONV_STREAMING)
     ya = host(a.process(dev(xs[0]), mode=gab.CONV_STREAMING))
     torch.cuda.synchronize()
-    assert b.scheme == "classic"                      # ... and says so (the NEXT launch's cut)
+    assert b.scheme == "split"
     assert np.abs(hy.numpy() - ya).max() <= 2e-6 * peak
     ya = host(a.process(dev(xs[1]), mode=gab.CONV_STREAMING))
     yb = host(b.process(dev(xs[1]), mode=gab.CONV_STREAMING))
     assert np.abs(ya - yb).max() <= 2e-6 * peak
-    # prepared arguments (what bench.py's timed loop uses) are the same call
+    # prepared arguments (a loop over a fixed set of buffers) are the same call
     args = b.prepare(dev(xs[0]), torch.empty(T * B, device="cuda"))
     b.launch(args)
     with pytest.raises(gab.GabError):
@@ -428,46 +429,6 @@ def test_conv_accel_split_and_classic_streams_agree(gab, orc):
         gab.ConvPlan(6, B, L, scheme="split")         # needs a channel count divisible by 4
     a.close()
     b.close()
-
-
-def test_conv_accel_channel_ranges_on_two_streams(gab, orc):
-    """gab_conv_process_range: a buffer launched as two channel ranges on two streams is the same
-    computation as one launch — same bits — over a stream of buffers."""
-    import torch
-    T, B, L = 64, 512, 4096
-    ir = dev(orc.conv_accel_ir(L, T))
-    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
-    a.set_ir(ir)
-    b.set_ir(ir)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    outs = [torch.empty(T * B, device="cuda") for _ in range(2)]
-    for i in range(12):
-        x = dev(orc.noise(T * B, seed=700 + i))
-        ya = host(a.process(x, mode=gab.CONV_STREAMING))
-        torch.cuda.synchronize()
-        yb = outs[i % 2]
-        b.process_range(x, yb, 0, 24, stream=s1)
-        b.process_range(x, yb, 24, 40, stream=s2)
-        b.advance()
-        torch.cuda.synchronize()
-        assert np.array_equal(bits(ya), bits(host(yb))), i
-    # the library-side loop over buffers and ranges is the same sequence of calls
-    xs = [dev(orc.noise(T * B, seed=800 + i)) for i in range(3)]
-    a.reset()
-    b.reset()
-    for i in range(5):
-        ya = host(a.process(xs[i % 3], mode=gab.CONV_STREAMING))
-    b.stream_ranges(xs, yb, [(0, 32), (32, 32)], [s1, s2], 5)
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(ya), bits(host(yb)))
-    with pytest.raises(gab.GabError):
-        b.process_range(x, yb, 2, 8)                  # ranges start and end on multiples of 4
-    c = gab.ConvPlan(T, B, L, scheme="classic")
-    c.set_ir(ir)
-    with pytest.raises(gab.GabError):
-        c.process_range(x, yb, 0, 32)
-    for p in (a, b, c):
-        p.close()
 
 
 def test_conv_accel_long_stream_does_not_drift(gab, orc):

@@ -37,11 +37,30 @@ def harness_sweep(gab, name, tracks_list, rows, iterations=30, **cfg):
         b.close()
 
 
-def conv_sweep(gab, tracks_list, rows, taps=4096, steps=400):
+def shard_checker(gab, taps):
+    """The tool's own row check (tools may not touch the oracle): the sampled channels again on a small
+    plan that holds the same rows of the global impulse-response bank — a shape the GPU tests pin to
+    the oracle; the columns must agree bit for bit.  tests/test_sweep_gpu.py runs the sweep with an
+    oracle-based checker instead."""
+    import numpy as np
+    import torch
+
+    def check(T, lo, n_s, ir_rows, x_rows, got):
+        shard = gab.ConvPlan(n_s, B, taps)
+        shard.set_ir(torch.from_numpy(np.ascontiguousarray(ir_rows).ravel()).cuda())
+        ok = True
+        for x, y in zip(x_rows, got):
+            ys = shard.process(torch.from_numpy(np.ascontiguousarray(x).ravel()).cuda()).view(B, n_s).cpu().numpy()
+            ok = ok and np.array_equal(y.view(np.uint32), ys.view(np.uint32)) and bool(np.isfinite(y).all())
+        shard.close()
+        return ok
+    return check
+
+
+def conv_sweep(gab, tracks_list, rows, taps=4096, steps=400, checker=None):
     """Streaming FFT convolution, `taps` taps.  Every row is VALIDATED: after the timed loop the
-    plan is reset and ten buffers go through it and through a 64-channel plan holding the same
-    rows of the global impulse-response bank (a shape the GPU tests pin to the oracle); the
-    sampled columns must agree bit for bit."""
+    plan is reset, ten buffers go through it and a sampled range of 64 channels is handed to
+    `checker(T, lo, n, ir_rows, x_rows, got)` (default: shard_checker)."""
     import numpy as np
     import torch
     rng = np.random.default_rng(taps)
@@ -77,19 +96,16 @@ def conv_sweep(gab, tracks_list, rows, taps=4096, steps=400):
             if i >= 10:
                 rt.append((time.perf_counter() - t1) * 1e3)
         wall = float(np.median(rt))
-        # ---- validation against a small shard
+        # ---- validation: ten buffers from a reset, a sampled channel range
         n_s = min(64, T)
         lo = 4 * int(rng.integers(0, (T - n_s) // 4 + 1))
-        shard = gab.ConvPlan(n_s, B, taps)
-        shard.set_ir(torch.from_numpy(np.ascontiguousarray(ir_host[lo:lo + n_s]).ravel()).cuda())
         plan.reset()
-        valid = True
+        x_rows, got = [], []
         for i in range(10):
             x = xs[i % 4]
-            y = plan.process(x, out=out).view(B, T)[:, lo:lo + n_s].contiguous()
-            ys = shard.process(x.view(T, B)[lo:lo + n_s].contiguous().view(-1)).view(B, n_s)
-            valid = valid and bool(torch.equal(y.view(torch.int32), ys.view(torch.int32))) and bool(torch.isfinite(out).all())
-        shard.close()
+            got.append(plan.process(x, out=out).view(B, T)[:, lo:lo + n_s].contiguous().cpu().numpy())
+            x_rows.append(x.view(T, B)[lo:lo + n_s].contiguous().cpu().numpy())
+        valid = bool((checker or shard_checker(gab, taps))(T, lo, n_s, ir_host[lo:lo + n_s], x_rows, got))
         alg = 4 * T * (2 * B + 2 * taps)
         rows.append(dict(benchmark="Conv1D_accel_stream_%d" % taps, tracks=T, wall_median_ms=wall,
                          wall_p95_ms=float(np.percentile(rt, 95)), device_median_ms=dev_ms,

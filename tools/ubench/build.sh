@@ -4,7 +4,6 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p tools/ubench/bin
 H=/opt/rocm/bin/hipcc
-$H -O2 -I include tools/ubench/two_chains.cpp -o tools/ubench/bin/two_chains -L gpuaudiobench_amd -lgab_hip -Wl,-rpath,'$ORIGIN/../../../gpuaudiobench_amd' -lpthread -Wno-implicit-const-int-float-conversion
 $H -O2 --offload-arch=gfx950 tools/ubench/library_baseline.cpp -o tools/ubench/bin/library_baseline -lhipfft
 $H -O3 --offload-arch=gfx950 -ffp-contract=off -I gpuaudiobench_amd/csrc -I include tools/ubench/mfma_dft.hip -o tools/ubench/bin/mfma_dft
 $H -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o tools/ubench/bin/valu_rate
