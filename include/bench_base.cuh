@@ -1,0 +1,5 @@
+// bench_base.cuh — the reference's header name (cuda/bench_base.cuh), forwarding to this repo's
+// HIP implementation of the same interface so that code written against the reference includes
+// compiles unchanged with hipcc.
+#pragma once
+#include "gab/bench_base.hpp"

@@ -1,0 +1,4 @@
+// bench_fdtd3d.cuh — the reference's header name (cuda/bench_fdtd3d.cuh), forwarding to the
+// benchmark classes of this repo (same class names, constructor signatures and defaults).
+#pragma once
+#include "gab/benchmarks.hpp"
