@@ -114,6 +114,7 @@ PROTOTYPES = {
     "gab_fdtd_emit": (_I, [_P, _P, _I, _I, _P]),
     "gab_fdtd_strip": (_I, [_P, C.POINTER(_P), C.POINTER(_I)]),
     "gab_generate_noise": (_I, [_P, _Z, C.c_uint]),
+    "gab_shard_range": (_I, [_I, _I, _Z, C.POINTER(_Z), C.POINTER(_Z)]),
     "gab_generate_conv1d_ir": (_I, [_P, _I, _Z, _Z, _Z]),
     "gab_generate_conv_accel_ir": (_I, [_P, _I, _Z, _Z, _Z]),
     "gab_calculate_statistics": (_I, [_P, _Z, C.POINTER(Statistics)]),

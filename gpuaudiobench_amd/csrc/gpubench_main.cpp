@@ -1,12 +1,16 @@
 // gpubench_main.cpp — command-line driver, flag-compatible with the reference's
 // cuda/main.cu:236-328 (--help --list --json --benchmark --fs --bufferSize
 // --nTracks --nRuns --outputfile; default benchmark RndMemRead; exit code 0/1),
-// plus the flags the BASELINE configs need: --irLength --fdtdGrid --convMode.
+// plus the flags the BASELINE configs need: --irLength --fdtdGrid --fdtdSteps
+// --convMode --gpus --validate-only --cpu-threads.  With --json the reference's object gains a
+// "roofline", a "cpu_golden" and (with --gpus) a "multi_gpu" member.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "gab/benchmarks.hpp"
+#include "gab/multi_gpu.hpp"
 
 namespace {
 
@@ -32,7 +36,13 @@ void printHelp() {
     printf("  --json              Output results in JSON format\n");
     printf("  --irLength [taps]   Impulse-response length for Conv1D / Conv1D_accel\n");
     printf("  --fdtdGrid [n]      FDTD3D grid edge including the boundary shell (default: 52)\n");
+    printf("  --fdtdSteps [n]     FDTD3D: leapfrog steps per iteration (3 per sample: sets the buffer to ceil(n/3) samples)\n");
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
+    printf("  --gpus [n]          Run on n devices, one host thread each: Conv1D_accel as contiguous channel shards of\n");
+    printf("                      --nTracks with the impulse-response bank broadcast once over RCCL; others as replicas\n");
+    printf("  --print-shards      Print the channel shards --gpus / --nTracks give and exit (no device is touched)\n");
+    printf("  --validate-only     Set up, validate against the CPU golden, exit 0/1; no timed loop\n");
+    printf("  --cpu-threads [n]   Threads for the timed CPU golden (default: all hardware threads; 0 = skip it)\n");
     printf("  --modalMode [m]     ModalFilterBank: placeholder (the CUDA port, default) | bank (real phasor bank)\n");
     printf("  --dawsim            Pace iterations to one buffer slot each (bufferSize / fs)\n");
     printf("  --dawsim-mode [m]   spin | sleep (default: spin)\n");
@@ -70,6 +80,42 @@ void printHelp() {
 static bool g_dawsim = false;
 static BenchmarkUtils::DAWSimulationMode g_dawsim_mode = BenchmarkUtils::DAWSimulationMode::SPIN;
 static double g_dawsim_jitter_us = 0.0;
+static bool g_validate_only = false;
+static int g_gpus = 0;              // 0: the reference's single-device path, no RCCL
+static bool g_validation_failed = false;
+static bool g_skip_cpu_golden = false;   // --cpu-threads 0
+
+// "roofline": {...} and "cpu_golden": {...} members for --json
+std::string extraMembers(GPUABenchmark& b, const GPUABenchmark::BenchmarkResult* result,
+                         const GPUABenchmark::ValidationData& validation) {
+    char buf[512];
+    std::string j;
+    const double bytes = static_cast<double>(b.algorithmicBytes());
+    const double dev_ms = (result && !result->gpu_latencies.empty()) ? result->gpu_statistics.median : 0.0;
+    if (dev_ms > 0.0) {
+        const double gbs = bytes / (dev_ms * 1e-3) / 1e9;
+        snprintf(buf, sizeof buf,
+                 "  \"roofline\": {\n    \"bound\": \"hbm\",\n    \"algorithmic_bytes\": %.0f,\n    \"device_median_ms\": %.6f,\n"
+                 "    \"achieved_GBps\": %.1f,\n    \"peak_GBps\": 8000.0,\n    \"frac\": %.4f\n  },\n", bytes, dev_ms, gbs, gbs / 8000.0);
+    } else {
+        snprintf(buf, sizeof buf, "  \"roofline\": {\n    \"bound\": \"hbm\",\n    \"algorithmic_bytes\": %.0f,\n"
+                                  "    \"device_median_ms\": null\n  },\n", bytes);
+    }
+    j += buf;
+    int used = 0;
+    const int want = CPU_THREADS > 0 ? CPU_THREADS : (int)std::max(1u, std::thread::hardware_concurrency());
+    const double cpu_ms = g_skip_cpu_golden ? -1.0 : b.timeCpuGolden(want, &used);
+    if (cpu_ms >= 0.0)
+        snprintf(buf, sizeof buf, "  \"cpu_golden\": {\n    \"ms\": %.4f,\n    \"threads\": %d,\n    \"speedup_vs_device\": %s\n  },\n",
+                 cpu_ms, used, dev_ms > 0.0 ? std::to_string(cpu_ms / dev_ms).c_str() : "null");
+    else
+        snprintf(buf, sizeof buf, "  \"cpu_golden\": null,\n");
+    j += buf;
+    snprintf(buf, sizeof buf, "  \"validation\": {\n    \"passed\": %s,\n    \"max_error\": %.6g\n  }",
+             validation.status == GPUABenchmark::ValidationStatus::SUCCESS ? "true" : "false", validation.max_error);
+    j += buf;
+    return j;
+}
 
 void runSelectedBenchmark(std::unique_ptr<GPUABenchmark> benchmark, const std::string& name) {
     try {
@@ -85,20 +131,34 @@ void runSelectedBenchmark(std::unique_ptr<GPUABenchmark> benchmark, const std::s
                    g_dawsim_mode == BenchmarkUtils::DAWSimulationMode::SPIN ? "spin" : "sleep",
                    sim.bufferDuration * 1e3, g_dawsim_jitter_us);
         }
-        printf("Running %s benchmark (%d iterations with %d warmup)...\n", name.c_str(), NRUNS, 3);
-        auto result = benchmark->runBenchmark(NRUNS, 3);
+        GPUABenchmark::BenchmarkResult result;
+        if (!g_validate_only) {
+            printf("Running %s benchmark (%d iterations with %d warmup)...\n", name.c_str(), NRUNS, 3);
+            result = benchmark->runBenchmark(NRUNS, 3);
+        }
 
         printf("Validating %s benchmark results...\n", name.c_str());
         GPUABenchmark::ValidationData validation;
         benchmark->validate(validation);
-        if (validation.status != GPUABenchmark::ValidationStatus::SUCCESS)
+        if (validation.status != GPUABenchmark::ValidationStatus::SUCCESS) {
             printf("Validation failed for %s:\n", name.c_str());
-        else
+            g_validation_failed = true;
+        } else {
             printf("Validation passed for %s\n", name.c_str());
+        }
         for (const auto& msg : validation.messages) printf("  %s\n", msg.c_str());
 
         if (JSON_OUTPUT) {
-            writeJSONResults(result.latencies, name, OUTPUT_FILE);
+            const std::string j = generateJSONResultsWith(result.latencies, name,
+                                                          extraMembers(*benchmark, g_validate_only ? nullptr : &result, validation));
+            if (OUTPUT_FILE.empty()) {
+                printf("%s\n", j.c_str());
+            } else {
+                FILE* f = fopen(OUTPUT_FILE.c_str(), "w");
+                if (f) { fputs(j.c_str(), f); fclose(f); printf("JSON results saved to: %s\n", OUTPUT_FILE.c_str()); }
+            }
+        } else if (g_validate_only) {
+            // nothing was timed
         } else {
             benchmark->printResults(result);
             benchmark->writeResults(result);
@@ -119,11 +179,52 @@ void runSelectedBenchmark(std::unique_ptr<GPUABenchmark> benchmark, const std::s
     }
 }
 
+// --gpus N: one host thread per device (include/gab/multi_gpu.hpp)
+int runOnSeveralDevices(const std::string& name) {
+    try {
+        gab::MultiGpuConfig cfg;
+        cfg.benchmark = name;
+        cfg.gpus = g_gpus;
+        cfg.iterations = NRUNS;
+        cfg.warmup = 3;
+        cfg.validate_only = g_validate_only;
+        const gab::MultiGpuReport rep = gab::runOnDevices(cfg);
+        printf("%s on %d device(s): %s; %zu tracks in all\n", name.c_str(), rep.gpus,
+               rep.sharded ? "contiguous channel shards, no per-buffer collective" : "replicas only", rep.total_tracks);
+        if (rep.ir_broadcast_ms >= 0.0)
+            printf("Impulse-response bank: %zu bytes broadcast with RCCL in %.3f ms (%.1f GB/s)\n", rep.ir_bank_bytes,
+                   rep.ir_broadcast_ms, rep.ir_bank_bytes / (rep.ir_broadcast_ms * 1e-3) / 1e9);
+        for (const auto& r : rep.ranks) {
+            printf("  device %d: tracks [%zu, %zu)  median %.4f ms  device %.4f ms  validation %s (max error %.3g)%s%s\n", r.device,
+                   r.tracks.lo, r.tracks.hi, r.result.latencies.empty() ? 0.0 : r.result.statistics.median,
+                   r.result.gpu_latencies.empty() ? 0.0 : r.result.gpu_statistics.median,
+                   r.validation.status == GPUABenchmark::ValidationStatus::SUCCESS ? "passed" : "FAILED", r.validation.max_error,
+                   r.error.empty() ? "" : "  error: ", r.error.c_str());
+            for (const auto& msg : r.validation.messages) printf("    %s\n", msg.c_str());
+        }
+        if (rep.job_median_ms > 0.0)
+            printf("Whole job: %.4f ms per buffer of all tracks (slowest rank), %.0f track-buffers/s\n", rep.job_median_ms,
+                   rep.tracks_per_second);
+        if (JSON_OUTPUT) {
+            const std::vector<float> none;
+            const std::string j = generateJSONResultsWith(rep.ranks.empty() ? none : rep.ranks[0].result.latencies, name,
+                                                          gab::multiGpuJson(rep));
+            if (OUTPUT_FILE.empty()) printf("%s\n", j.c_str());
+            else if (FILE* f = fopen(OUTPUT_FILE.c_str(), "w")) { fputs(j.c_str(), f); fclose(f); }
+        }
+        return rep.ok() ? 0 : 1;
+    } catch (const std::exception& e) {
+        printf("Benchmark %s failed: %s\n", name.c_str(), e.what());
+        return 1;
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     printf("GPGPU Audio Benchmark\n");
     std::string which = "RndMemRead";
+    bool print_shards = false;
 
     for (int i = 1; i < argc; i++) {
         const bool hasNext = i + 1 < argc;
@@ -151,6 +252,20 @@ int main(int argc, char** argv) {
             printf("Output file set to: %s\n", OUTPUT_FILE.c_str());
         } else if (strcmp(argv[i], "--irLength") == 0) { if (!need("--irLength")) return 1; IR_LENGTH = atoi(argv[++i]); }
         else if (strcmp(argv[i], "--fdtdGrid") == 0) { if (!need("--fdtdGrid")) return 1; FDTD_GRID = atoi(argv[++i]); }
+        else if (strcmp(argv[i], "--fdtdSteps") == 0) { if (!need("--fdtdSteps")) return 1; FDTD_STEPS = atoi(argv[++i]); }
+        else if (strcmp(argv[i], "--gpus") == 0) {
+            if (!need("--gpus")) return 1;
+            g_gpus = atoi(argv[++i]);
+            if (g_gpus < 1) { printf("Error: --gpus must be >= 1\n"); return 1; }
+        }
+        else if (strcmp(argv[i], "--print-shards") == 0) { print_shards = true; }
+        else if (strcmp(argv[i], "--validate-only") == 0) { g_validate_only = true; }
+        else if (strcmp(argv[i], "--cpu-threads") == 0) {
+            if (!need("--cpu-threads")) return 1;
+            CPU_THREADS = atoi(argv[++i]);
+            if (CPU_THREADS < 0) { printf("Error: --cpu-threads must be >= 0\n"); return 1; }
+            g_skip_cpu_golden = CPU_THREADS == 0;
+        }
         else if (strcmp(argv[i], "--convMode") == 0) {
             if (!need("--convMode")) return 1;
             CONV_STREAMING = strcmp(argv[++i], "stateless") == 0 ? 0 : 1;
@@ -178,6 +293,21 @@ int main(int argc, char** argv) {
         return 1;
     }
 
+    if (FDTD_STEPS > 0 && which == "FDTD3D") {
+        // the reference advances 3 leapfrog steps per audio sample (bench_fdtd3d.cuh:41)
+        BUFSIZE = (FDTD_STEPS + 2) / 3;
+        printf("FDTD3D: %d steps asked for -> %d samples x 3 steps = %d steps per iteration\n", FDTD_STEPS, BUFSIZE, 3 * BUFSIZE);
+    }
+    if (print_shards) {
+        const int world = g_gpus > 0 ? g_gpus : 1;
+        if ((size_t)world > (size_t)NTRACKS) { printf("Error: more GPUs than tracks\n"); return 1; }
+        for (int r = 0; r < world; ++r) {
+            const gab::ShardRange s = gab::shardRange(r, world, (size_t)NTRACKS);
+            printf("shard %d: tracks [%zu, %zu) = %zu\n", r, s.lo, s.hi, s.count());
+        }
+        return 0;
+    }
+
     int deviceCount = 0;
     hipError_t err = hipGetDeviceCount(&deviceCount);
     if (err != hipSuccess) {
@@ -185,6 +315,13 @@ int main(int argc, char** argv) {
         return 1;
     }
     printf("Found %d HIP device(s)\n", deviceCount);
+
+    if (g_gpus > 0) {
+        printf("Running %s benchmark on %d device(s)...\n", which.c_str(), g_gpus);
+        const int rc = runOnSeveralDevices(which);
+        printf("Done\n");
+        return rc;
+    }
 
     std::unique_ptr<GPUABenchmark> instance;
     try {
@@ -197,7 +334,7 @@ int main(int argc, char** argv) {
         printf("Running %s benchmark...\n", which.c_str());
         runSelectedBenchmark(std::move(instance), which);
         printf("Done\n");
-        return 0;
+        return (g_validate_only && g_validation_failed) ? 1 : 0;
     }
     printf("Error: Unknown benchmark '%s'\n", which.c_str());
     printf("Use --list to see available benchmarks.\n");

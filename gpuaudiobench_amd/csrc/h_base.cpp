@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <iomanip>
+#include <thread>
 
 #include "gab/bench_base.hpp"
 #include "gab_c_api.h"
@@ -143,6 +144,35 @@ GPUABenchmark::BenchmarkResult GPUABenchmark::runWithIteration(int iterations, i
     r.throughput_gbps = (r.bytes_processed / (1024.0 * 1024.0 * 1024.0)) / seconds;   // GiB/s, as the reference prints it
     r.samples_per_sec = samples / seconds;
     return r;
+}
+
+// Times the CPU golden on the host: the tracks cut over `threads` threads where the golden is
+// separable by track, otherwise the whole golden on one thread (as the reference runs it).
+double GPUABenchmark::timeCpuGolden(int threads, int* threads_used) {
+    const size_t T = track_count_;
+    size_t n = static_cast<size_t>(threads < 1 ? 1 : threads);
+    if (n > T) n = T;
+    auto t0 = std::chrono::steady_clock::now();
+    bool ok = false;
+    if (cpuGoldenSlice(0, 0)) {                       // a zero-track probe: "can be cut"
+        std::vector<std::thread> pool;
+        std::vector<char> done(n, 0);
+        t0 = std::chrono::steady_clock::now();
+        for (size_t k = 0; k < n; ++k) {
+            const size_t lo = T * k / n, hi = T * (k + 1) / n;
+            auto work = [this, lo, hi, k, &done]() { done[k] = cpuGoldenSlice(lo, hi - lo) ? 1 : 0; };
+            if (k + 1 < n) pool.emplace_back(work); else work();
+        }
+        for (auto& th : pool) th.join();
+        ok = std::all_of(done.begin(), done.end(), [](char c) { return c != 0; });
+    } else {
+        n = 1;
+        t0 = std::chrono::steady_clock::now();
+        ok = cpuGoldenWhole();
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (threads_used) *threads_used = static_cast<int>(n);
+    return ok ? ms : -1.0;
 }
 
 void GPUABenchmark::writeResults(const BenchmarkResult& result, const std::string& filename) {

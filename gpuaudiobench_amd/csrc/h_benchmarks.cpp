@@ -104,6 +104,13 @@ void GainBenchmark::setupBenchmark() {
     say("Gain benchmark setup complete (gain = %.1f)\n", BenchmarkConstants::GAIN_VALUE);
 }
 
+bool GainBenchmark::cpuGoldenSlice(size_t first, size_t count) {
+    if (!cpu_reference) return false;
+    const size_t B = getBufferSize();
+    gab::golden::gain(getHostInput() + first * B, cpu_reference + first * B, count * B, BenchmarkConstants::GAIN_VALUE);
+    return true;
+}
+
 void GainBenchmark::runKernel() { performBenchmarkIteration(); }
 
 void GainBenchmark::performBenchmarkIteration() {
@@ -150,6 +157,14 @@ void GainStatsBenchmark::setupBenchmark() {
     gab::golden::gainstats(getHostInput(), cpu_reference, cpu_stats_reference, getTrackCount(), getBufferSize());
     say("GainStats benchmark setup complete (gain = %.1f, computing mean + max per track)\n",
         BenchmarkConstants::GAINSTATS_GAIN);
+}
+
+bool GainStatsBenchmark::cpuGoldenSlice(size_t first, size_t count) {
+    if (!cpu_reference) return false;
+    const size_t B = getBufferSize();
+    gab::golden::gainstats(getHostInput() + first * B, cpu_reference + first * B, cpu_stats_reference + first * NSTATS,
+                           count, B);
+    return true;
 }
 
 void GainStatsBenchmark::runKernel() { performBenchmarkIteration(); }
@@ -228,6 +243,12 @@ void DataTransferBenchmark::setupBenchmark() {
         config_.name, input_size, config_.inputRatio * 100.0f, output_size, config_.outputRatio * 100.0f);
 }
 
+bool DataTransferBenchmark::cpuGoldenWhole() {
+    if (!cpu_reference) return false;
+    gab::golden::datatransfer(h_input_var, cpu_reference, input_size, output_size);
+    return true;
+}
+
 void DataTransferBenchmark::runKernel() { performBenchmarkIteration(); }
 
 // pinned hipHostMalloc buffers + hipMemcpyAsync: H2D, kernel and D2H are queued
@@ -281,6 +302,14 @@ void FFTBenchmark::setupBenchmark() {
     cpu_reference_imag = allocateHostBuffer<float>(output_fft_size, "fft cpu reference imag");
     gab::golden::dft1024(h_input_fft, cpu_reference_real, cpu_reference_imag, getTrackCount());
     say("FFT benchmark setup complete (FFT size = %d, %zu tracks)\n", FFT_SIZE, getTrackCount());
+}
+
+bool FFTBenchmark::cpuGoldenSlice(size_t first, size_t count) {
+    if (!cpu_reference_real) return false;
+    const size_t bins = FFT_SIZE / 2 + 1;
+    gab::golden::dft1024(h_input_fft + first * FFT_SIZE, cpu_reference_real + first * bins, cpu_reference_imag + first * bins,
+                         count);
+    return true;
 }
 
 void FFTBenchmark::runKernel() { performBenchmarkIteration(); }
@@ -376,6 +405,15 @@ void IIRBenchmark::setupBenchmark() {
     say("IIR filter benchmark setup complete (biquad lowpass filter)\n");
 }
 
+bool IIRBenchmark::cpuGoldenSlice(size_t first, size_t count) {
+    if (!cpu_reference) return false;
+    const size_t B = getBufferSize();
+    std::memset(cpu_state_reference + first * STATES_PER_TRACK, 0, sizeof(float) * count * STATES_PER_TRACK);
+    gab::golden::iir(getHostInput() + first * B, cpu_reference + first * B, h_coeffs,
+                     cpu_state_reference + first * STATES_PER_TRACK, static_cast<int>(count), static_cast<int>(B));
+    return true;
+}
+
 void IIRBenchmark::runKernel() { performBenchmarkIteration(); }
 
 void IIRBenchmark::resetState() {
@@ -437,6 +475,13 @@ void Conv1DBenchmark::setupBenchmark() {
     say("Conv1D benchmark setup complete (IR length = %d, taps staged through LDS)\n", ir_length_);
 }
 
+bool Conv1DBenchmark::cpuGoldenSlice(size_t first, size_t count) {
+    if (!cpu_reference) return false;
+    gab::golden::conv1d_rows(getHostInput(), h_ir_buf, cpu_reference, ir_length_, static_cast<int>(getBufferSize()),
+                             static_cast<int>(first), static_cast<int>(first + count), static_cast<int>(getTrackCount()));
+    return true;
+}
+
 void Conv1DBenchmark::runKernel() { performBenchmarkIteration(); }
 
 void Conv1DBenchmark::performBenchmarkIteration() {
@@ -490,7 +535,9 @@ Conv1DAccelBenchmark::~Conv1DAccelBenchmark() {
 void Conv1DAccelBenchmark::setupBenchmark() {
     say("Setting up Conv1D accelerated benchmark...\n");
     allocateBuffers(getTotalElements());
-    generateTestData(42);
+    // a shard takes its rows of the one flat noise stream over ALL tracks (cuda/bench_utils.cu:238-245)
+    BenchmarkUtils::generateRandomAudioDataFrom(getHostInput(), getTotalElements(), 42,
+                                                static_cast<unsigned long long>(track_offset_) * getBufferSize());
     h_ir_buf = allocateHostBuffer<float>(ir_buffer_size, "conv1d_accel host IR buffer");
     d_ir_buf = allocateDeviceBuffer<float>(ir_buffer_size, "conv1d_accel device IR buffer");
     cpu_reference = allocateHostBuffer<float>(getTotalElements(), "conv1d_accel cpu reference");
@@ -498,11 +545,23 @@ void Conv1DAccelBenchmark::setupBenchmark() {
                              ir_length_), "gab_conv_create");
     BenchmarkUtils::generateConvAccelImpulseResponses(h_ir_buf, ir_length_, track_offset_, getTrackCount(),
                                                       total_tracks_);
-    HIP_CHECK(hipMemcpyAsync(d_ir_buf, h_ir_buf, ir_buffer_bytes, hipMemcpyHostToDevice, stream_));
-    checkGab(gab_conv_set_ir(plan_, d_ir_buf, stream_), "gab_conv_set_ir");   // spectra bank, once
+    if (d_shared_ir_) {
+        checkGab(gab_conv_set_ir(plan_, d_shared_ir_, stream_), "gab_conv_set_ir");   // rows of the broadcast bank
+    } else {
+        HIP_CHECK(hipMemcpyAsync(d_ir_buf, h_ir_buf, ir_buffer_bytes, hipMemcpyHostToDevice, stream_));
+        checkGab(gab_conv_set_ir(plan_, d_ir_buf, stream_), "gab_conv_set_ir");   // spectra bank, once
+    }
     gab::golden::conv_accel(getHostInput(), h_ir_buf, cpu_reference, ir_length_,
                             static_cast<int>(getBufferSize()), static_cast<int>(getTrackCount()));
     say("Conv1D accelerated benchmark setup complete.\n");
+}
+
+bool Conv1DAccelBenchmark::cpuGoldenSlice(size_t first, size_t count) {
+    if (!cpu_reference) return false;
+    gab::golden::conv_accel_rows(getHostInput(), h_ir_buf, cpu_reference, ir_length_, static_cast<int>(getBufferSize()),
+                                 static_cast<int>(first), static_cast<int>(first + count),
+                                 static_cast<int>(getTrackCount()));
+    return true;
 }
 
 void Conv1DAccelBenchmark::runKernel() { performBenchmarkIteration(); }
@@ -583,6 +642,15 @@ ModalBenchmark::ModalBenchmark(Variant variant)
 ModalBenchmark::~ModalBenchmark() {
     freeHostBuffers({h_mode_params, h_modal_output, cpu_reference});
     freeDeviceBuffers({d_mode_params, d_modal_output, d_workspace});
+}
+
+bool ModalBenchmark::cpuGoldenWhole() {
+    if (!cpu_reference) return false;
+    std::vector<float> scratch(modal_output_size);
+    const int B = static_cast<int>(getBufferSize());
+    if (variant_ == Variant::BANK) gab::golden::modal_bank(h_mode_params, scratch.data(), num_modes_, B, out_tracks_);
+    else gab::golden::modal(h_mode_params, scratch.data(), num_modes_, B, out_tracks_);
+    return true;
 }
 
 void ModalBenchmark::setupBenchmark() {
@@ -926,6 +994,14 @@ void RndMemBenchmark::setupBenchmark() {
     cpu_reference = allocateHostBuffer<float>(T * B, "rndmem cpu reference");
     gab::golden::rndmem(h_sample_memory, h_playheads, cpu_reference, static_cast<int>(B), static_cast<int>(T));
     say("RndMem benchmark setup complete (512MB sample memory, %zu tracks, random access)\n", T);
+}
+
+bool RndMemBenchmark::cpuGoldenWhole() {
+    if (!cpu_reference) return false;
+    std::vector<float> scratch(getTotalElements());      // the playheads have moved on since setup
+    gab::golden::rndmem(h_sample_memory, h_playheads, scratch.data(), static_cast<int>(getBufferSize()),
+                        static_cast<int>(getTrackCount()));
+    return true;
 }
 
 void RndMemBenchmark::initializePlayheads() {

@@ -97,10 +97,9 @@ void iir(const float* in, float* out, const IIRCoefficients* c, float* state, in
     }
 }
 
-void conv1d(const float* in, const float* ir, float* out, int L, int B, int T) {
-    std::memset(out, 0, sizeof(float) * static_cast<size_t>(T) * B);
+void conv1d_rows(const float* in, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T) {
     const long total = static_cast<long>(T) * B;
-    for (int t = 0; t < T; ++t)
+    for (int t = t_lo; t < t_hi; ++t)
         for (int i = 0; i < B; ++i) {
             float samp = 0.0f;
             for (int j = 0; j < L; ++j) {
@@ -111,8 +110,13 @@ void conv1d(const float* in, const float* ir, float* out, int L, int B, int T) {
         }
 }
 
-void conv_accel(const float* in, const float* ir, float* out, int L, int B, int T) {
-    for (int t = 0; t < T; ++t)
+void conv1d(const float* in, const float* ir, float* out, int L, int B, int T) {
+    std::memset(out, 0, sizeof(float) * static_cast<size_t>(T) * B);
+    conv1d_rows(in, ir, out, L, B, 0, T, T);
+}
+
+void conv_accel_rows(const float* in, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T) {
+    for (int t = t_lo; t < t_hi; ++t)
         for (int s = 0; s < B; ++s) {
             float acc = 0.0f;
             for (int k = 0; k < L; ++k) {
@@ -122,6 +126,10 @@ void conv_accel(const float* in, const float* ir, float* out, int L, int B, int 
             }
             out[static_cast<size_t>(T) * s + t] = acc;
         }
+}
+
+void conv_accel(const float* in, const float* ir, float* out, int L, int B, int T) {
+    conv_accel_rows(in, ir, out, L, B, 0, T, T);
 }
 
 void modal(const float* params, float* out, int n_modes, int B, int out_tracks) {

@@ -27,6 +27,9 @@ void dft1024_f64(const float* in, double* re, double* im, size_t tracks);       
 void iir(const float* in, float* out, const IIRCoefficients* c, float* state, int T, int B);  // bench_iir.cu:170-197
 void conv1d(const float* in, const float* ir, float* out, int L, int B, int T);  // bench_conv1d.cu:188-208
 void conv_accel(const float* in, const float* ir, float* out, int L, int B, int T);  // bench_conv1d_accel.cu:234-252
+// the same loops for tracks [t_lo, t_hi) only (the CPU baseline cuts the tracks over threads)
+void conv1d_rows(const float* in, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T);
+void conv_accel_rows(const float* in, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T);
 void modal(const float* params, float* out, int n_modes, int B, int out_tracks); // bench_modal.cu:152-179
 // the real bank: metal-swift/MetalSwiftBench/Benchmarks/ModalFilterBankBenchmark.swift:73-101
 void modal_bank(const float* params, float* out, int n_modes, int B, int out_tracks);

@@ -28,6 +28,8 @@ int IR_LENGTH = 0;
 int FDTD_GRID = 0;
 int CONV_STREAMING = 1;
 int MODAL_REAL = 0;
+int FDTD_STEPS = 0;
+int CPU_THREADS = 0;
 bool GAB_QUIET = false;
 
 namespace {
@@ -120,6 +122,15 @@ std::string generateJSONResults(const std::vector<float>& vec, const std::string
     j += "  }\n";
     j += "}\n";
     return j;
+}
+
+std::string generateJSONResultsWith(const std::vector<float>& vec, const std::string& benchmarkName,
+                                    const std::string& extra_members) {
+    std::string j = generateJSONResults(vec, benchmarkName);
+    if (extra_members.empty()) return j;
+    const size_t close = j.rfind("  }\n}");              // the end of "deadline" and of the object
+    if (close == std::string::npos) return j;
+    return j.substr(0, close) + "  },\n" + extra_members + "\n}\n";
 }
 
 void writeJSONResults(const std::vector<float>& vec, const std::string& benchmarkName,
@@ -349,6 +360,13 @@ void BenchmarkConfig::print() const {
 // ---- generators -----------------------------------------------------------------
 void generateRandomAudioData(float* buffer, size_t samples, unsigned int seed) {
     std::mt19937 gen(seed);
+    std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
+    for (size_t i = 0; i < samples; ++i) buffer[i] = dist(gen);
+}
+
+void generateRandomAudioDataFrom(float* buffer, size_t samples, unsigned int seed, unsigned long long skip) {
+    std::mt19937 gen(seed);
+    gen.discard(skip);                         // one engine draw per float (generate_canonical<float,24>)
     std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
     for (size_t i = 0; i < samples; ++i) buffer[i] = dist(gen);
 }

@@ -109,6 +109,13 @@ public:
     virtual void resetState() {}
     virtual void runValidationIteration() { resetState(); performBenchmarkIteration(); }
     virtual size_t algorithmicBytes() const { return 2 * getTotalElements() * sizeof(float); }
+    // The CPU golden of tracks [first, first + count) recomputed into the benchmark's own reference
+    // buffer (what setupBenchmark already did once); false when the golden cannot be cut by track.
+    // timeCpuGolden() runs it over `threads` host threads (1 when it cannot be cut) and returns the
+    // wall time in ms, or a negative value when the benchmark offers no golden to time.
+    virtual bool cpuGoldenSlice(size_t first_track, size_t count) { (void)first_track; (void)count; return false; }
+    virtual bool cpuGoldenWhole() { return false; }
+    double timeCpuGolden(int threads, int* threads_used = nullptr);
 
     // DAW-style pacing (metal-swift Core/GPUABenchmark.swift:90,358-392): when set, every
     // warm-up and timed iteration is followed by a wait for the next buffer slot.

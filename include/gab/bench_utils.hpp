@@ -183,6 +183,9 @@ struct BenchmarkConfig {
 
 // ---- data generation (cuda/bench_utils.cuh:213-240) ----------------------------
 void generateRandomAudioData(float* buffer, size_t samples, unsigned int seed = 42);
+// The same stream from its `skip`-th value on: a channel shard takes its rows of the one flat
+// track-major stream the reference draws over ALL tracks (additive).
+void generateRandomAudioDataFrom(float* buffer, size_t samples, unsigned int seed, unsigned long long skip);
 
 enum class WindowType { RECTANGULAR, HAMMING, HANN, BLACKMAN };
 void generateImpulseResponse(float* buffer, int length, float frequency,

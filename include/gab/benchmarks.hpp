@@ -48,6 +48,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenSlice(size_t first_track, size_t count) override;
     const float* cpuReference() const { return cpu_reference; }
 
 private:
@@ -67,6 +68,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenSlice(size_t first_track, size_t count) override;
     size_t algorithmicBytes() const override;
     const float* hostStats() const { return h_stats; }
     const float* cpuStatsReference() const { return cpu_stats_reference; }
@@ -103,6 +105,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenWhole() override;
     size_t algorithmicBytes() const override;
     int inputSize() const { return input_size; }
     int outputSize() const { return output_size; }
@@ -132,6 +135,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenSlice(size_t first_track, size_t count) override;
     size_t algorithmicBytes() const override;
     // max over bins of |dre|+|dim| against a float64 DFT of the same input,
     // for the product output and for the reference-style fp32 golden
@@ -169,6 +173,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenSlice(size_t first_track, size_t count) override;
     void resetState() override;
     size_t algorithmicBytes() const override;
     const IIRCoefficients& coefficients() const { return *h_coeffs; }
@@ -198,6 +203,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenSlice(size_t first_track, size_t count) override;
     size_t algorithmicBytes() const override;
     int irLength() const { return ir_length_; }
 
@@ -228,8 +234,13 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenSlice(size_t first_track, size_t count) override;
     void resetState() override;
     size_t algorithmicBytes() const override;
+    // Multi-GPU runs: the impulse responses of this shard already lie on this device (its rows of the
+    // bank that was broadcast over RCCL); setupBenchmark() then transforms those instead of uploading
+    // its own copy.  The golden still uses the host formula, so validate() cross-checks the bank.
+    void shareImpulseResponses(const float* d_rows) { d_shared_ir_ = d_rows; }
     int irLength() const { return ir_length_; }
     int fftSize() const { return fft_size_; }
     int overlapSize() const { return overlap_size_; }
@@ -246,6 +257,7 @@ private:
     float* d_ir_buf = nullptr;
     float* cpu_reference = nullptr;
     gab_conv_plan* plan_ = nullptr;
+    const float* d_shared_ir_ = nullptr;
     size_t ir_buffer_size;
     size_t ir_buffer_bytes;
     float peak_norm_error_ = 0.0f;
@@ -272,6 +284,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenWhole() override;
     size_t algorithmicBytes() const override;
     int modeCount() const { return num_modes_; }
     int outputTracks() const { return out_tracks_; }
@@ -446,6 +459,7 @@ public:
     void runKernel() override;
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
+    bool cpuGoldenWhole() override;
     void resetState() override;
 
 private:

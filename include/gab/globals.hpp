@@ -36,3 +36,9 @@ void writeCSVResults(const std::vector<float>& vec, const std::string& benchmark
 void writeJSONResults(const std::vector<float>& vec, const std::string& benchmarkName,
                       const std::string& filename = "");
 std::string generateJSONResults(const std::vector<float>& vec, const std::string& benchmarkName);
+// The reference's object with further members appended before its closing brace (additive):
+// `extra_members` is the text of one or more `"key": value` members, comma-separated, no trailing comma.
+std::string generateJSONResultsWith(const std::vector<float>& vec, const std::string& benchmarkName,
+                                    const std::string& extra_members);
+extern int FDTD_STEPS;           // --fdtdSteps    (<=0: bufferSize samples x 3 steps, as the reference)
+extern int CPU_THREADS;          // --cpu-threads  (<=0: every hardware thread) for the timed CPU golden

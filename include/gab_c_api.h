@@ -263,6 +263,10 @@ int gab_generate_conv1d_ir(float* h_ir, int ir_len, size_t track_offset,
 int gab_generate_conv_accel_ir(float* h_ir, int ir_len, size_t track_offset,
                                size_t n_tracks, size_t total_tracks);
 
+/* Channel shards of a multi-GPU job (additive; BASELINE configs[4]): the contiguous range
+ * [*lo, *hi) of `rank` out of `world`, the remainder going to the low ranks.  Host arithmetic.  */
+int gab_shard_range(int rank, int world, size_t total_tracks, size_t* lo, size_t* hi);
+
 /* calculateStatistics (cuda/bench_utils.cu:358-414): mean, median, sample
  * std-dev, min, max, linearly interpolated p95/p99.                          */
 typedef struct {

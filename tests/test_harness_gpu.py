@@ -138,3 +138,51 @@ def test_modal_real_bank_through_the_harness(gab, tracks):
     assert r.gpu_median_ms > 0
     assert b.algorithmic_bytes() == min(1024 * tracks, 1 << 20) * 32 + min(tracks, 32) * 128 * 4
     b.close()
+
+
+def _json_of(stdout):
+    start = stdout.index('{\n  "benchmark"')
+    return json.loads(stdout[start:stdout.index("\n}\n", start) + 3])
+
+
+def test_driver_conv_accel_on_devices_with_rccl_broadcast():
+    """gpubench --gpus 1 goes through the whole multi-device path on one device: ncclCommInitAll,
+    the impulse-response bank uploaded to device 0 and broadcast with ncclBroadcast, a host thread
+    per device, the rank transforming its rows of the bank; validation (against the golden made
+    from the host formula) cross-checks the broadcast bank.  N > 1 is unmeasured (one-GPU boxes)."""
+    r = run_driver("--benchmark", "Conv1D_accel", "--irLength", "4096", "--nTracks", "1024", "--gpus", "1",
+                   "--nRuns", "20", "--json")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    d = _json_of(r.stdout)
+    m = d["multi_gpu"]
+    assert m["gpus"] == 1 and m["total_tracks"] == 1024 and "ncclBroadcast" in m["collective"]
+    assert m["ir_bank_bytes"] == 1024 * 4096 * 4 and m["ir_broadcast_ms"] is not None and m["ir_broadcast_ms"] >= 0
+    assert m["ranks"] == [dict(m["ranks"][0], device=0, first_track=0, tracks=1024, valid=True)]
+    assert m["ranks"][0]["max_error"] <= 1e-5 and m["ranks"][0]["algorithmic_bytes"] == 4 * 1024 * (2 * 512 + 2 * 4096)
+    assert m["job_median_ms"] > 0 and m["tracks_per_second"] > 0
+    # asking for more devices than the box has is refused with a clear message
+    r = run_driver("--benchmark", "Conv1D_accel", "--gpus", "64")
+    assert r.returncode == 1 and "HIP device(s) present" in r.stdout
+    # replicas: a benchmark without channel structure
+    r = run_driver("--benchmark", "DWG1DAccel", "--gpus", "1", "--nRuns", "5")
+    assert r.returncode == 0 and "replicas only" in r.stdout
+
+
+def test_driver_json_carries_roofline_and_cpu_golden():
+    r = run_driver("--benchmark", "Conv1D_accel", "--irLength", "4096", "--nTracks", "256", "--nRuns", "10", "--json",
+                   "--cpu-threads", "4")
+    assert r.returncode == 0, r.stdout[-2000:]
+    d = _json_of(r.stdout)
+    assert d["roofline"]["algorithmic_bytes"] == 4 * 256 * (2 * 512 + 2 * 4096)
+    assert d["roofline"]["device_median_ms"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_golden"]["threads"] == 4 and d["cpu_golden"]["ms"] > 0
+    assert d["validation"]["passed"] is True and d["validation"]["max_error"] <= 1e-5
+    r = run_driver("--benchmark", "gain", "--nRuns", "5", "--json", "--cpu-threads", "0")
+    assert _json_of(r.stdout)["cpu_golden"] is None
+
+
+def test_driver_validate_only_and_fdtd_steps():
+    r = run_driver("--benchmark", "FDTD3D", "--fdtdGrid", "32", "--fdtdSteps", "30", "--validate-only")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "30 steps asked for -> 10 samples x 3 steps = 30 steps" in r.stdout
+    assert "Validation passed for FDTD3D" in r.stdout and "Running FDTD3D benchmark (" not in r.stdout

@@ -167,3 +167,36 @@ def test_trace_period_tool_on_a_synthetic_trace(tmp_path):
     assert abs(d["avg_kernel_duration_us"] - 7.0) < 1e-9
     assert abs(d["period_us_per_buffer"] - (8000 * 99 + 3000 + 7000) / 100 / 1e3) < 1e-9
     assert 1.7 < d["avg_kernels_in_flight"] < 1.76
+
+
+def test_driver_shard_arithmetic_and_flags_without_a_gpu():
+    """gpubench --print-shards (no device is touched) and gab_shard_range agree with the Python side's
+    sharding.shard_range; flag validation happens before any device call."""
+    import ctypes as C
+    import subprocess
+    from gpuaudiobench_amd import sharding, _capi
+    exe = os.path.join(os.path.dirname(os.path.abspath(gab.__file__)), "gpubench")
+    for world, total in [(1, 128), (3, 1000), (8, 8192), (5, 7), (4, 4)]:
+        r = subprocess.run([exe, "--print-shards", "--gpus", str(world), "--nTracks", str(total)],
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout
+        got = [ln for ln in r.stdout.splitlines() if ln.startswith("shard ")]
+        assert len(got) == world
+        covered = 0
+        for rank, ln in enumerate(got):
+            lo, hi = sharding.shard_range(rank, world, total)
+            assert ln == "shard %d: tracks [%d, %d) = %d" % (rank, lo, hi, hi - lo)
+            a, b = C.c_size_t(0), C.c_size_t(0)
+            assert _capi.lib.gab_shard_range(rank, world, total, C.byref(a), C.byref(b)) == 0
+            assert (a.value, b.value) == (lo, hi) and lo == covered
+            covered = hi
+        assert covered == total
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    assert _capi.lib.gab_shard_range(3, 3, 10, C.byref(a), C.byref(b)) == _capi.GAB_ERR_INVALID_ARG
+    assert _capi.lib.gab_shard_range(0, 0, 10, C.byref(a), C.byref(b)) == _capi.GAB_ERR_INVALID_ARG
+    for bad in (["--gpus", "0"], ["--gpus"], ["--cpu-threads", "-2"], ["--print-shards", "--gpus", "9", "--nTracks", "4"]):
+        r = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "Error" in r.stdout, (bad, r.stdout)
+    help_text = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=60).stdout
+    for flag in ("--gpus", "--fdtdSteps", "--validate-only", "--cpu-threads", "--print-shards"):
+        assert flag in help_text
