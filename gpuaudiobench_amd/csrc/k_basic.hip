@@ -151,6 +151,9 @@ __global__ __launch_bounds__(kBlock) void modal_placeholder_kernel(const float* 
 // different XCDs every edge line crossed the fabric twice (FETCH_SIZE 1.54x the algorithmic reads).
 // The 1-D grid is therefore walked so that the sample tiles of a track tile are CONSECUTIVE
 // workgroups of ONE XCD (blocks b and b+8 share an XCD): they meet in that XCD's L2.
+// (Round 3, measured and not kept: 16-byte accesses — a lane reading four consecutive samples through
+// an unaligned dwordx4 load and storing four neighbouring tracks — 54.8 us against 46.5 at 65 536
+// tracks: the unaligned wide loads are split and cost more than the instructions they save.)
 __global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict__ pool,
                                                        const int* __restrict__ playheads,
                                                        float* __restrict__ out, int T, int B) {

@@ -41,7 +41,7 @@ namespace {
 
 // px = pitch of a vx row (nx + 4); z0 = global z of the first plane a launch covers (a z-slab of
 // a decomposed grid launches only its own planes; nz stays the GLOBAL depth for the boundary tests)
-struct Grid { int nx, ny, nz, px, z0; int stagger = 0; };   // stagger: 10 ns ticks that odd planes start late (LDS-halo kernel)
+struct Grid { int nx, ny, nz, px, z0; };
 
 struct Fields { float *p, *vx, *vy, *vz; };
 
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void fdtd_step_vec4_kernel(Fields o, Fields n,
 // vy row segment in LDS, threads of the first / last row add the halo rows above and below, and
 // p(x +/- 1), p(y +/- 1), vy(y + 1) then come from LDS instead of five more global loads.  Same
 // arithmetic, same bits.
-template <int LX, int ROWS>
+template <int LX, int ROWS, bool HOIST>
 __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fields n, Grid g, float c1,
                                                                  float c2, float damp, size_t src, size_t rcv,
                                                                  const float* __restrict__ add_next,
@@ -254,14 +254,6 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     __shared__ float sp[(ROWS + 2) * W];               // pressure rows y0-1 .. y0+ROWS
     __shared__ float svy[(ROWS + 1) * W];              // vy rows y0 .. y0+ROWS
     const int tx = threadIdx.x, ty = threadIdx.y;
-    // When the whole step is resident at once (C4: 1024 workgroups, four per CU) the launch is a read
-    // burst followed by a write burst.  Starting the odd planes `stagger` x 10 ns late lets one half's
-    // stores run under the other half's loads: 13.8 -> 12.9 us per step at 128^3 (2 us; 1.5 and 2.5 us
-    // gain half as much, staggering by resident round or in four phases loses).  Time-bounded wait.
-    if (g.stagger > 0 && (blockIdx.z & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(4);
-    }
     const int y0 = blockIdx.y * ROWS, y = y0 + ty, z = blockIdx.z + g.z0;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const int x0 = 4 * tx;
@@ -280,11 +272,21 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     float* const vrow = svy + ty * W + 4 + x0;
 
     float4 pc4 = make_float4(0.f, 0.f, 0.f, 0.f), vy4 = pc4, vx4 = pc4, vz4 = pc4;
+    // HOIST: the z-neighbour planes and the vx face beyond the quad are requested with everything
+    // else, so that the step pays ONE memory round trip (they are needed after the barrier only)
+    float4 h_pzm = pc4, h_pzp = pc4, h_vzp = pc4;
+    float h_vx4 = 0.0f;
     if (live) {
         pc4 = ld4(o.p + pi);
         vy4 = ld4(o.vy + iy);
         vx4 = ld4(o.vx + ix);
         vz4 = ld4(o.vz + iz);
+        if constexpr (HOIST) {
+            h_vx4 = o.vx[ix + 4];
+            if (z > 0) h_pzm = ld4(o.p + pi - sxy);
+            if (z < nz - 1) h_pzp = ld4(o.p + pi + sxy);
+            h_vzp = ld4(o.vz + iz + sxy);
+        }
         lds4(prow, pc4);
         lds4(vrow, vy4);
         if (ty == 0 && y > 0) lds4(prow - W, ld4(o.p + pi - nx));                          // row y0-1
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     if (!live) return;
 
     const float pc[4] = {pc4.x, pc4.y, pc4.z, pc4.w};
-    float fx[5] = {vx4.x, vx4.y, vx4.z, vx4.w, o.vx[ix + 4]};
+    float fx[5] = {vx4.x, vx4.y, vx4.z, vx4.w, HOIST ? h_vx4 : o.vx[ix + 4]};
     float fy[4] = {vy4.x, vy4.y, vy4.z, vy4.w};
     float fz[4] = {vz4.x, vz4.y, vz4.z, vz4.w};
     if (x0 > 0) fx[0] = __builtin_fmaf(-c1, __fsub_rn(pc[0], prow[-1]), fx[0]);
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
         for (int j = 0; j < 4; ++j) fy[j] = __builtin_fmaf(-c1, __fsub_rn(pc[j], pm[j]), fy[j]);
     }
     if (z > 0) {
-        const float4 q = ld4(o.p + pi - sxy);
+        const float4 q = HOIST ? h_pzm : ld4(o.p + pi - sxy);
         const float pm[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) fz[j] = __builtin_fmaf(-c1, __fsub_rn(pc[j], pm[j]), fz[j]);
@@ -324,13 +326,13 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     st4(n.vz + iz, fz[0], fz[1], fz[2], fz[3]);
     if (!has_right) n.vx[ix + 4] = fx[4];
     if (y == ny - 1) *reinterpret_cast<float4*>(n.vy + iy + nx) = *reinterpret_cast<const float4*>(vrow + W);
-    if (z == nz - 1) *reinterpret_cast<float4*>(n.vz + iz + sxy) = ld4(o.vz + iz + sxy);
+    if (z == nz - 1) *reinterpret_cast<float4*>(n.vz + iz + sxy) = HOIST ? h_vzp : ld4(o.vz + iz + sxy);
 
     float pv[4];
     const bool row_interior = y > 0 && y < ny - 1 && z > 0 && z < nz - 1;
     if (row_interior) {
-        const float4 pyp = *reinterpret_cast<const float4*>(prow + W), pzp = ld4(o.p + pi + sxy);
-        const float4 vyp = *reinterpret_cast<const float4*>(vrow + W), vzp = ld4(o.vz + iz + sxy);
+        const float4 pyp = *reinterpret_cast<const float4*>(prow + W), pzp = HOIST ? h_pzp : ld4(o.p + pi + sxy);
+        const float4 vyp = *reinterpret_cast<const float4*>(vrow + W), vzp = HOIST ? h_vzp : ld4(o.vz + iz + sxy);
         const float py[4] = {pyp.x, pyp.y, pyp.z, pyp.w}, pz[4] = {pzp.x, pzp.y, pzp.z, pzp.w};
         const float hyo[4] = {vyp.x, vyp.y, vyp.z, vyp.w}, hzo[4] = {vzp.x, vzp.y, vzp.z, vzp.w};
 #pragma unroll
@@ -616,6 +618,11 @@ int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin,
     return GAB_OK;
 }
 
+// LDS-halo kernel: the z-neighbour planes are requested before the barrier, with the cell's own
+// loads — one memory round trip per step instead of two: 12.9 -> 11.7 us per step at 128^3 (the
+// 2 us stagger of odd planes that round 2 used to overlap loads and stores then only costs time)
+constexpr bool kFdtdHoist = true;
+
 // One leapfrog step old -> new over the plan's own planes, with the kernel form that suits the row
 // width (see the kernels above).
 void launch_step(const gab_fdtd_plan* f, hipStream_t q, const gab::Fields& cur, const gab::Fields& nxt,
@@ -624,9 +631,11 @@ void launch_step(const gab_fdtd_plan* f, hipStream_t q, const gab::Fields& cur, 
     const int nzl = f->z_end - f->z_begin;
     gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, f->z_begin};
 #ifdef GAB_ABLATE
-    static const int stagger_env = getenv("GAB_FDTD_STAGGER") ? atoi(getenv("GAB_FDTD_STAGGER")) : -1;
+    static const bool hoist = getenv("GAB_FDTD_HOIST") ? atoi(getenv("GAB_FDTD_HOIST")) != 0 : kFdtdHoist;
+    static const int tile_env = getenv("GAB_FDTD_TILE_THREADS") ? atoi(getenv("GAB_FDTD_TILE_THREADS")) : 0;
 #else
-    constexpr int stagger_env = -1;
+    constexpr bool hoist = kFdtdHoist;
+    constexpr int tile_env = 0;
 #endif
     const size_t sxy = (size_t)P.nx * P.ny;
     const size_t src = P.source_z * sxy + (size_t)P.source_y * P.nx + P.source_x;
@@ -640,16 +649,20 @@ void launch_step(const gab_fdtd_plan* f, hipStream_t q, const gab::Fields& cur, 
     if (vec4 && f->lds_tiles && tx > 16 && tx <= 64) {
         // whole x extent in one workgroup: LX x ROWS threads, (ROWS + 2) pressure rows in LDS
 #define GAB_FDTD_LDS_LAUNCH(LX, ROWS)                                                                 \
-    gab::fdtd_step_lds_kernel<LX, ROWS><<<dim3(1, (P.ny + ROWS - 1) / ROWS, nzl), dim3(LX, ROWS, 1), 0, q>>>( \
-        cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out)
+    do {                                                                                              \
+        if (hoist)                                                                                    \
+            gab::fdtd_step_lds_kernel<LX, ROWS, true><<<dim3(1, (P.ny + ROWS - 1) / ROWS, nzl), dim3(LX, ROWS, 1), 0, q>>>( \
+                cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out);  \
+        else                                                                                          \
+            gab::fdtd_step_lds_kernel<LX, ROWS, false><<<dim3(1, (P.ny + ROWS - 1) / ROWS, nzl), dim3(LX, ROWS, 1), 0, q>>>( \
+                cur, nxt, g, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, damp, src, rcv, add_next, strip_out); \
+    } while (0)
         // 512-thread tiles (half as many halo rows) once they still make >= 4 workgroups
         // per CU; 256-thread tiles below that (measured: 13.6 vs 14.3 us/step at 128^3,
         // 47.5 vs 49.6 at 200^3, but 9.5 vs 8.8 at 96^3)
         const int lx = tx <= 32 ? 32 : 64;
-        const bool big = (long)((P.ny + 512 / lx - 1) / (512 / lx)) * nzl >= 1024;
-        // one resident round of 512-thread workgroups (769..1024 of them): stagger the odd planes
-        const long wgs = (long)((P.ny + 512 / lx - 1) / (512 / lx)) * nzl;
-        g.stagger = stagger_env >= 0 ? stagger_env : ((big && wgs > 768 && wgs <= 1024) ? 200 : 0);
+        bool big = (long)((P.ny + 512 / lx - 1) / (512 / lx)) * nzl >= 1024;
+        if (tile_env) big = tile_env == 512;
         if (lx == 32 && big) GAB_FDTD_LDS_LAUNCH(32, 16);
         else if (lx == 32) GAB_FDTD_LDS_LAUNCH(32, 8);
         else if (big) GAB_FDTD_LDS_LAUNCH(64, 8);

@@ -340,32 +340,75 @@ __device__ __forceinline__ void dwg_step(float& f, float& b, float x, bool injec
     b = nb;
 }
 
+// Where sample s of waveguide g reaches the output tap: s = first[g] + k * period[g].  The mix kernel
+// reads this pair instead of the 32-byte record and a modulo per (sample, waveguide).
+__device__ __forceinline__ void dwg_publish_hits(const WG& wg, int g, int2* __restrict__ hits) {
+    int f = wg.outTap - wg.writePos % wg.length;
+    if (f < 0) f += wg.length;
+    // a tap outside the line is never reached
+    hits[g] = make_int2((wg.outTap >= 0 && wg.outTap < wg.length) ? f : 0x7fffffff, wg.length);
+}
+
+// The reference form: one thread per waveguide walks the samples in order.  Consecutive samples touch
+// consecutive cells, so a run of up to 16 samples (fewer than the line is long) reads 16 DIFFERENT
+// cell pairs: their loads are issued together instead of one dependent round trip per sample.  Lanes
+// of a wave walk DIFFERENT lines (8 KB apart), every access is its own cache line, so a workgroup is
+// 16 threads: the waveguides spread over four times as many CUs' address paths (140 -> 61 us at 128
+// waveguides with the runs alone).  Same operations in the same order per cell: bit-identical.
 __global__ __launch_bounds__(64) void dwg_naive_kernel(const WG* __restrict__ wgs,
                                                       float* __restrict__ fwd, float* __restrict__ bwd,
                                                       const float* __restrict__ input,
-                                                      float* __restrict__ ws, int n_wg, int B,
+                                                      float* __restrict__ ws, int2* __restrict__ hits, int n_wg, int B,
                                                       int max_len) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_wg) return;
     const WG wg = wgs[g];
+    dwg_publish_hits(wg, g, hits);
     float* F = fwd + (size_t)g * max_len;
     float* Bk = bwd + (size_t)g * max_len;
-    for (int s = 0; s < B; ++s) {
-        int cur = (wg.writePos + s) % wg.length;
-        int bp = (cur + wg.length / 2) % wg.length;
+    const int L = wg.length;
+    constexpr int U = 16;
+    int cur = wg.writePos % L;
+    int bp = (cur + L / 2) % L;
+    int s = 0;
+    if (L >= 2 * U) {                        // a run never meets its own cells again (forward or backward line)
+        for (; s + U <= B; s += U) {
+            float f[U], b[U], x[U];
+            int c[U], d[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                c[j] = cur; d[j] = bp;
+                f[j] = F[cur]; b[j] = Bk[bp];
+                x[j] = input[s + j];
+                cur = cur + 1 == L ? 0 : cur + 1;
+                bp = bp + 1 == L ? 0 : bp + 1;
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                float mix;
+                dwg_step(f[j], b[j], __fmul_rn(x[j], wg.gain), c[j] == wg.inTap, wg, mix);
+                F[c[j]] = f[j];
+                Bk[d[j]] = b[j];
+                if (c[j] == wg.outTap) ws[(size_t)g * B + s + j] = mix;
+            }
+        }
+    }
+    for (; s < B; ++s) {
         float f = F[cur], b = Bk[bp], mix;
         float x = __fmul_rn(input[s], wg.gain);
         dwg_step(f, b, x, cur == wg.inTap, wg, mix);
         F[cur] = f;
         Bk[bp] = b;
         if (cur == wg.outTap) ws[(size_t)g * B + s] = mix;
+        cur = cur + 1 == L ? 0 : cur + 1;
+        bp = bp + 1 == L ? 0 : bp + 1;
     }
 }
 
 __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ wgs,
                                                        float* __restrict__ fwd, float* __restrict__ bwd,
                                                        const float* __restrict__ input,
-                                                       float* __restrict__ ws, int n_wg, int B,
+                                                       float* __restrict__ ws, int2* __restrict__ hits, int n_wg, int B,
                                                        int max_len) {
     __shared__ float xin[2048];                       // staged input (B <= 2048), else global
     const int g = blockIdx.y;
@@ -375,12 +418,11 @@ __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ w
         for (int i = threadIdx.x; i < B; i += blockDim.x) xin[i] = input[i];
         __syncthreads();
     }
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;       // delay-line cell
-    if (p >= wg.length) return;
-    // first sample that lands on cell p: (writePos + s) % L == p
-    int s = p - (wg.writePos % wg.length);
-    if (s < 0) s += wg.length;
-    if (s >= B) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) dwg_publish_hits(wg, g, hits);
+    // thread j owns the j-th cell the buffer visits: cell (writePos + j) % L, first touched by sample j
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= wg.length || s >= B) return;
+    const int p = (wg.writePos % wg.length + s) % wg.length;
     const int bp = (p + wg.length / 2) % wg.length;
     float* F = fwd + (size_t)g * max_len + p;
     float* Bk = bwd + (size_t)g * max_len + bp;
@@ -395,11 +437,11 @@ __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ w
     *Bk = b;
 }
 
-// One wavefront per output sample.  Lanes test 64 waveguides at a time for "does
-// sample s land on your output tap"; the (few) that do are added in waveguide
-// order via ballot + readlane, so the sum is the golden's ordered sum without a
-// serial scan over every waveguide.
-__global__ __launch_bounds__(256) void dwg_mix_kernel(const WG* __restrict__ wgs,
+// One wavefront per output sample.  Lanes test 64 waveguides at a time for "does sample s land on
+// your output tap" — s = first[g] + k * period[g], two coalesced words per waveguide, a modulo only
+// for lines shorter than the buffer — and the (few) that do are added in waveguide order via ballot
+// + readlane, so the sum is the golden's ordered sum without a serial scan over every waveguide.
+__global__ __launch_bounds__(256) void dwg_mix_kernel(const int2* __restrict__ hits,
                                                      const float* __restrict__ ws,
                                                      float* __restrict__ out, int n_wg, int B,
                                                      int out_tracks) {
@@ -408,20 +450,28 @@ __global__ __launch_bounds__(256) void dwg_mix_kernel(const WG* __restrict__ wgs
     if (s >= B) return;
     float acc = 0.0f;
     const int n = n_wg < out_tracks ? n_wg : out_tracks;
-    for (int g0 = 0; g0 < n; g0 += 64) {
-        const int g = g0 + lane;
-        bool hit = false;
-        float v = 0.0f;
-        if (g < n) {
-            const int L = wgs[g].length;
-            hit = ((wgs[g].writePos + s) % L) == wgs[g].outTap;
-            if (hit) v = ws[(size_t)g * B + s];
+    constexpr int U = 8;                               // chunks of 64 waveguides requested together:
+    for (int g0 = 0; g0 < n; g0 += 64 * U) {           // the scan is a chain of dependent loads otherwise
+        int2 h[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int g = g0 + 64 * k + lane;
+            h[k] = g < n ? hits[g] : make_int2(0x7fffffff, 1);
         }
-        unsigned long long m = __ballot(hit);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            acc = __fadd_rn(acc, __shfl(v, src, 64));
-            m &= m - 1;
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int g = g0 + 64 * k + lane;
+            const int d = s - h[k].x;                  // h.x: first sample on the tap, h.y: the line's length
+            const bool hit = d == 0 || (d >= h[k].y && (d % h[k].y) == 0);
+            unsigned long long m = __ballot(hit);
+            if (m) {                                   // wave-uniform
+                const float v = hit ? ws[(size_t)g * B + s] : 0.0f;
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    acc = __fadd_rn(acc, __shfl(v, src, 64));
+                    m &= m - 1;
+                }
+            }
         }
     }
     if (lane == 0) out[s] = acc;
@@ -484,7 +534,8 @@ int gab_conv1d(const float* d_in, float* d_out, const float* d_ir, int ir_len, i
 
 size_t gab_dwg_workspace_bytes(int n_waveguides, int bufsize) {
     if (n_waveguides <= 0 || bufsize <= 0) return 0;
-    return sizeof(float) * (size_t)n_waveguides * (size_t)bufsize;
+    // tap contributions [n][B] (padded to 8 bytes), then where each waveguide's output tap is reached: (first, period)[n]
+    return sizeof(float) * ((((size_t)n_waveguides * (size_t)bufsize) + 1) & ~(size_t)1) + 2 * sizeof(int) * (size_t)n_waveguides;
 }
 
 int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const float* d_in,
@@ -499,18 +550,19 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
         hipStream_t s = gab::as_stream(stream);
         const gab::WG* wgs = reinterpret_cast<const gab::WG*>(d_wg);
         float* ws = static_cast<float*>(d_workspace);
+        int2* hits = reinterpret_cast<int2*>(ws + (((size_t)n_waveguides * bufsize + 1) & ~(size_t)1));
         if (variant == GAB_DWG_NAIVE) {
-            gab::dwg_naive_kernel<<<(n_waveguides + 63) / 64, 64, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws,
+            gab::dwg_naive_kernel<<<(n_waveguides + 15) / 16, 16, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits,
                                                                          n_waveguides, bufsize, max_len);
         } else {
-            int cells = max_len < bufsize ? max_len : bufsize;   // a cell >= B is never visited
+            int cells = max_len < bufsize ? max_len : bufsize;   // a buffer visits min(L, B) cells of a line
             dim3 grid((cells + 255) / 256, n_waveguides);
-            gab::dwg_cells_kernel<<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, n_waveguides,
+            gab::dwg_cells_kernel<<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, n_waveguides,
                                                        bufsize, max_len);
         }
         int rc = gab::launch_status("dwg kernel");
         if (rc) return rc;
-        gab::dwg_mix_kernel<<<(bufsize + 3) / 4, 256, 0, s>>>(wgs, ws, d_out, n_waveguides, bufsize,
+        gab::dwg_mix_kernel<<<(bufsize + 3) / 4, 256, 0, s>>>(hits, ws, d_out, n_waveguides, bufsize,
                                                               out_tracks);
         return gab::launch_status("dwg_mix_kernel");
     });

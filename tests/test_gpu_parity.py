@@ -550,6 +550,30 @@ def test_dwg_delay_lines_bit_exact(gab, orc, variant):
 
 
 @pytest.mark.parametrize("variant", ["naive", "accel"])
+def test_dwg_write_position_late_in_the_line(gab, orc, variant):
+    """A write position near the END of a long line: the buffer then visits cells beyond the first
+    B of the line (and wraps); input and output taps sit inside that visited range.  Delay lines
+    and mix bit-exact over three buffers, for lines shorter and longer than the buffer."""
+    import torch
+    n_wg, B, ML = 70, 256, 2000
+    wg, x = orc.dwg_init(n_wg, B)
+    L = wg["length"].astype(np.int64)
+    wg["writePos"] = np.where(np.arange(n_wg) % 2 == 0, L - 7, L // 2 + 11) % L
+    wg["inputTapPos"] = (wg["writePos"] + 5) % L
+    wg["outputTapPos"] = (wg["writePos"] + np.where(np.arange(n_wg) % 3 == 0, 5, 40)) % L
+    v = gab.DWG_NAIVE if variant == "naive" else gab.DWG_ACCEL
+    fwd_r, bwd_r = np.zeros(n_wg * ML, np.float32), np.zeros(n_wg * ML, np.float32)
+    fwd, bwd = torch.zeros(n_wg * ML, device="cuda"), torch.zeros(n_wg * ML, device="cuda")
+    for it in range(3):
+        y = host(gab.dwg(dev(wg.view(np.uint8)), fwd, bwd, dev(x), B, ML, variant=v))
+        ry = orc.dwg(wg, fwd_r, bwd_r, x, B, ML)
+        assert np.array_equal(bits(y), bits(ry)), it
+        assert np.array_equal(bits(host(fwd)), bits(fwd_r)), it
+        assert np.array_equal(bits(host(bwd)), bits(bwd_r)), it
+    assert np.abs(ry).max() > 0 and fwd_r.any()
+
+
+@pytest.mark.parametrize("variant", ["naive", "accel"])
 def test_dwg_audible_configuration(gab, orc, variant):
     """The reference's tap placement never lets energy reach the output tap
     (SURVEY §8c); move the output tap onto the input tap and start the write
