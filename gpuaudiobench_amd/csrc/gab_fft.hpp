@@ -503,6 +503,12 @@ struct Wave1024Twiddles {
     cf w1;         // W64^(j&3): its powers are re-formed in the pass (registers)
     cf w2[15];     // W1024^(j i), i = 1..15
 };
+// Two registers instead of sixteen: both passes re-form their powers from the base (the same
+// powers_of, so the same values) — for kernels whose waves carry other state across transforms.
+struct Wave1024TwiddlesLean {
+    cf w1;         // W64^(j&3)
+    cf w2b;        // W1024^j
+};
 
 template <bool INV>
 struct WaveFFT1024 {
@@ -524,9 +530,29 @@ struct WaveFFT1024 {
         const cf b = t.w2[0];
         powers_of<16>(b, t.w2);
     }
+    using Lean = Wave1024TwiddlesLean;
+    __device__ static __forceinline__ void load_twiddles(Lean& t, const cf* __restrict__ tw, int lane) {
+        t.w1 = tw[(lane & 3) * (kTwiddleN / 64)];
+        t.w2b = tw[lane * (kTwiddleN / 1024)];
+    }
+    __device__ static __forceinline__ void last_pass_twiddles(const Twiddles& t, cf (&w)[15]) {
+#pragma unroll
+        for (int r = 0; r < 15; ++r) w[r] = t.w2[r];
+    }
+    __device__ static __forceinline__ void last_pass_twiddles(const Lean& t, cf (&w)[15]) {
+        cf b = t.w2b;
+        asm volatile("" : "+v"(b.x), "+v"(b.y));          // pinned to the pass, like w1's
+        powers_of<16>(b, w);
+    }
 
-    __device__ static __forceinline__ void run(cf (&v)[16], cf* __restrict__ img, const Twiddles& t,
-                                               int lane_in) {
+    struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+    // `hook(i)` runs at the transform's two exchange points (i = 0, 1), after the wave's LDS writes and
+    // before its reads: a caller whose workgroup shares ONE hardware barrier between roles arrives at
+    // that barrier there, so that a transform spans three barrier intervals instead of one.
+    template <class Hook = NoHook, class TW = Twiddles>
+    __device__ static __forceinline__ void run(cf (&v)[16], cf* __restrict__ img, const TW& t,
+                                               int lane_in, Hook hook = Hook()) {
         unsigned lane = (unsigned)lane_in;
         asm volatile("" : "+v"(lane));
         // pass 0: butterflies b = lane + 64 m on v[m + 4 i]; y[4 b + i]
@@ -541,6 +567,7 @@ struct WaveFFT1024 {
                 for (int i = 0; i < 4; ++i) img[wb + 272 * m + i] = v[m + 4 * i];
         }
         __builtin_amdgcn_wave_barrier();
+        hook(0);
         const unsigned rb = lane + (lane >> 4);         // Pad(lane + 64 r) = rb + 68 r
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = img[rb + 68 * r];
@@ -560,10 +587,15 @@ struct WaveFFT1024 {
             for (int k = 0; k < 16; ++k) img[wb + 4 * k + (k >> 2)] = v[Butterfly<16, INV>::out_slot(k)];
         }
         __builtin_amdgcn_wave_barrier();
+        hook(1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = img[rb + 68 * r];
+        {
+            cf w2[15];
+            last_pass_twiddles(t, w2);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) v[r] = INV ? cmulc(v[r], t.w2[r - 1]) : cmul(v[r], t.w2[r - 1]);
+            for (int r = 1; r < 16; ++r) v[r] = INV ? cmulc(v[r], w2[r - 1]) : cmul(v[r], w2[r - 1]);
+        }
         Butterfly<16, INV>::run(v);
         __builtin_amdgcn_wave_barrier();
         cf o[16];

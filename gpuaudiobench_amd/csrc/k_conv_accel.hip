@@ -597,42 +597,62 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
                                        (head + nb) & (kSlots - 1), lds);
 }
 
-// ---- split cut, n buffers per launch: both roles of a duo in ONE resident workgroup -----------------
-// gab_conv_process_batch on a split plan.  A workgroup of 512 threads owns a duo for the whole launch:
-// waves 0-3 run the near role (as conv_split_kernel's near workgroups do), waves 4-7 the far role of
-// the pair whose turn it is; the far share they park is picked up by their own near waves one and two
-// buffers later, so nothing crosses workgroups and the launch needs no boundary between buffers —
-// workgroups drift apart instead of loading and computing in lockstep.  The two roles share the
-// workgroup's one hardware barrier: per buffer every wave executes exactly kBatchBarriers s_barriers
-// (the far role's five are those of its transforms; the near role has two of its own and three
-// placed where the far role's fall in time), plus one that closes the buffer.  Same arithmetic, same
-// order as conv_split_kernel: bit-identical to n launches of it.
-constexpr int kBatchBarriers = 5;      // per buffer and wave, before the closing one
+// ---- split cut, n buffers per launch: a duo of channel pairs in ONE resident workgroup -------------------
+// gab_conv_process_batch on a split plan (bench.py's `value`).  A workgroup owns a duo for the whole launch,
+// so the parked far share never leaves it and nothing needs a kernel boundary between buffers.  Same
+// arithmetic, same order as conv_split_kernel — bit-identical to n launches of it — with fewer bytes, fewer
+// transforms, and every role's work cut to the barrier intervals of the far role's transform:
+//  * A2's window at buffer k, [k-2 | k-1], IS A's window at buffer k-1, so its spectrum is the one A's
+//    wave left in its LDS image a buffer earlier: the A2 product is formed from that image before the
+//    next forward transform overwrites it (the first buffer of a launch gets it from a prologue transform
+//    of the ring's blocks).  Same inputs, same operations: bit-identical.  One forward transform per pair
+//    and buffer instead of two;
+//  * the previous block stays in registers, so the near role loads only the NEW block of every buffer
+//    (a per-buffer launch reads every input block as k, k-1 and k-2);
+//  * the carry ring of the duo lives in LDS for the whole launch (32 KB): the far share never goes to
+//    memory between buffers; it is loaded at entry and written back at exit;
+//  * the near role is a pipeline of two waves per pair: the FORWARD wave (A2 product, forward transform,
+//    A product, sum) hands the output spectrum of buffer k to the INVERSE wave through LDS, which turns it
+//    into samples one period later, while the forward wave is already on buffer k+1.  A launch of n
+//    buffers therefore runs n + 1 periods (the far and forward waves idle in the last one).
+// (Round 2's form — near role on four waves with both near transforms per pair, carry ring in memory,
+// 6.4 us per buffer — is in the history of this file; this one runs 5.3.)
+// Workgroup = 512 threads: waves 0-1 forward (pair 0, pair 1), waves 2-3 inverse, waves 4-7 far — one
+// near and one far wave per SIMD.  Every wave executes kBatchBarriers s_barriers per period; a
+// wave-held transform arrives at two of them from inside (WaveFFT1024's hook), so that each role does
+// about one transform pass per barrier interval.
+constexpr int kBatchBarriers = 6;
+constexpr int kBatchThreads = 2 * kThreads;
+constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;      // cf entries (151 KB)
 
-__global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
+struct ArriveAtBarrier { __device__ __forceinline__ void operator()(int) const { __syncthreads(); } };
+
+__global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
-    __shared__ cf lds[4 * kWaveImg + 2 * kLdsHalf];
+    __shared__ cf lds[kBatchLds];
+    cf* const far_x = lds + 6 * kWaveImg;
+    cf* const far_y = far_x + kLdsHalf;
+    cf* const carry = far_y + kLdsHalf;                               // [pair of the duo][slot][512]
     const int tid = threadIdx.x;
-    const bool far = tid >= kThreads;                                 // uniform per wave
     const int d = xcd_contiguous(blockIdx.x, gridDim.x);
     const size_t step = (size_t)T * kB;
-    // Inputs of the launch are all there, so the two newest blocks of any window come straight from
-    // the input buffers (the ring only serves older blocks, and the launches that follow), and each
-    // role requests the NEXT buffer's operands as soon as its spectral product has freed the registers
-    // (partner values, spectra): the loads fly under the inverse transform.
+    cf* const carry_g = sp.carry + (size_t)(2 * d) * kCarrySlots * kB;   // the duo's two rings are contiguous
+    for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry[i] = carry_g[i];
+    __syncthreads();
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
 
-    if (far) {
+    if (w >= 4) {
+        // ---- far waves: F of the pair whose turn it is (window = blocks k-7 .. k; the two newest straight from
+        // the input buffers, the next buffer's operands requested under the inverse transform); the share is
+        // parked in LDS
         const int ft = tid - kThreads;
         using FB = fft::BlockFFT<kNB, 16, false>;
         using FBi = fft::BlockFFT<kNB, 16, true>;
-        cf* const X = lds + 4 * kWaveImg;
-        cf* const Y = X + kLdsHalf;
-        // powers of the first twiddled pass are re-formed in the pass (the same products, the same
-        // values): the registers hold the next window instead
         typename FB::Mixed twb;
         FB::load_twiddles(twb, tw, ft);
-        // window of buffer nb for the pair whose turn it is: blocks k-7 .. k, oldest first
         auto load_window = [&](int nb, cf (&z)[16], float4 (&c)[16]) {
             const int head = (head0 + nb) & (kSlots - 1);
             const int q = 2 * d + (head & 1);
@@ -655,140 +675,195 @@ __global__ __launch_bounds__(2 * kThreads, 2) void conv_split_batch_kernel(
                 z[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
             load_spectra<kNB, 16>(c, sp.pmF + (size_t)q * kBinsB, ft);
         };
-        cf zb[16], zn[16];                                            // zn: partner values, then the next window
+        cf zb[16], zn[16];
         float4 cb[16];
         load_window(0, zb, cb);
         for (int nb = 0; nb < n_buffers; ++nb) {
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(4)) {                                        // diagnostic builds: far role idle
+                for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
+                continue;
+            }
+#endif
             const int head = (head0 + nb) & (kSlots - 1);
-            const int q = 2 * d + (head & 1);
-            cf* const cp = sp.carry + (size_t)q * kCarrySlots * kB;
-            FB::run(zb, X, Y, twb, ft);                               // 2 barriers
-            partner_exchange<kNB, 16, true>(zb, zn, X, ft);           // 1 barrier
+            cf* const cp = carry + (head & 1) * kCarrySlots * kB;
+            FB::run(zb, far_x, far_y, twb, ft);                       // barriers 1, 2
+            partner_exchange<kNB, 16, true>(zb, zn, far_x, ft);       // barrier 3
             spectral_product<kNB, 16>(zb, zn, cb, ft);
             __builtin_amdgcn_sched_barrier(0);
             if (nb + 1 < n_buffers) load_window(nb + 1, zn, cb);      // flies under the inverse transform
             __builtin_amdgcn_sched_barrier(0);
-            FBi::template run<typename FB::Mixed, 4>(zb, Y, X, twb, ft);     // 2 barriers; only [12..15]
-            cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;          // block k+1
-            cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;          // block k+2
+            FBi::template run<typename FB::Mixed, 4>(zb, far_y, far_x, twb, ft);   // barriers 4, 5; only [12..15]
+            cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;              // block k+1
+            cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;              // block k+2
             c1[ft] = zb[12];
             c1[ft + kThreads] = zb[13];
             c2[ft] = zb[14];
             c2[ft + kThreads] = zb[15];
-            __syncthreads();                                          // closes the buffer
+            __syncthreads();                                          // barrier 6 closes the period
 #pragma unroll
             for (int r = 0; r < 16; ++r) zb[r] = zn[r];
         }
-        return;
-    }
-
-    // ---- near waves: wave w holds one 1024-point transform: pair (w >> 1) of the duo, window w & 1
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = 2 * d + (w >> 1);
-    const int ta = 2 * q, tb = ta + 1;
-    const bool second = (w & 1) != 0;
-    cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
-    cf* const img = lds + w * kWaveImg;
-    using WF = fft::WaveFFT1024<false>;
-    using WFi = fft::WaveFFT1024<true>;
-    WF::Twiddles t;
-    WF::load_twiddles(t, tw, lane);
-    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
-    const float4* const pm = (second ? sp.pmA2 : pmA) + (size_t)q * kBinsA;
-    // a block of this pair as complex (channel a, channel b): from input buffer nb - back when that
-    // lies inside the launch, from the ring otherwise
-    auto load_block = [&](int nb, int back, cf* z8) {
-        if (nb - back >= 0) {
-            const float* const xa = in + (nb - back) * step + (size_t)ta * kB;
-            const float* const xb = xa + kB;
+        for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // the pipeline's last period
+    } else if (w < 2) {
+        // ---- forward waves: wave w holds pair w of the duo
+        const int q = 2 * d + w;
+        cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const img = lds + w * kWaveImg;                           // the transform's exchanges, then its spectrum
+        cf* const hand = lds + (2 + w) * kWaveImg;                    // output spectrum for the inverse wave
+        using WF = fft::WaveFFT1024<false>;
+        WF::Lean t;
+        WF::load_twiddles(t, tw, lane);
+        const float4* const pa = pmA + (size_t)q * kBinsA;
+        const float4* const pa2 = sp.pmA2 + (size_t)q * kBinsA;
+        const float* const xa0 = in + (size_t)(2 * q) * kB;           // channel a of buffer 0; channel b is kB further
+        cf z[16], prev[8], nxt[8];
+        float4 c[16];
+        {   // prologue: the spectrum of the ring's blocks [k-2 | k-1] into the image
+            const int s1 = ((head0 + kSlots - 1) & (kSlots - 1)) * kB, s2 = ((head0 + kSlots - 2) & (kSlots - 1)) * kB;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z8[j] = mk(xa[lane + 64 * j], xb[lane + 64 * j]);
-        } else {
-            const int s = ((head0 + nb - back) & (kSlots - 1)) * kB;
+            for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z8[j] = hp[s + lane + 64 * j];
-        }
-    };
-    auto load_window = [&](int nb, cf (&z)[16]) {                     // A: [k-1 | k]; A2: [k-2 | k-1]
-        load_block(nb, second ? 2 : 1, &z[0]);
-        load_block(nb, second ? 1 : 0, &z[8]);
-    };
-    cf z[16], zn[16];                                                 // zn: partner values, then the next window
-    load_window(0, z);
-    for (int nb = 0; nb < n_buffers; ++nb) {
-        const int head = (head0 + nb) & (kSlots - 1);
-        float* const outb = out + nb * step;
-        float4 c[16];                                                 // spectra: not needed before the product
-        load_spectra<kNA, 16>(c, pm, lane);
-        if (!second) {                                                // the new block enters the ring
+            for (int j = 0; j < 8; ++j) prev[j] = hp[s1 + lane + 64 * j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = z[8 + j];
-        }
-        __syncthreads();                                              // (1) beside the far role's first pass
-        WF::run(z, img, t, lane);
-        __syncthreads();                                              // (2) beside its second pass
+            for (int j = 0; j < 8; ++j) nxt[j] = mk(xa0[lane + 64 * j], xa0[kB + lane + 64 * j]);
+            load_spectra<kNA, 16>(c, pa2, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zn[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
-        spectral_product<kNA, 16>(z, zn, c, lane);
-        __builtin_amdgcn_wave_barrier();
-        if (second) {
+            for (int j = 0; j < 8; ++j) z[8 + j] = prev[j];
+            WF::run(z, img, t, lane, WF::NoHook());
 #pragma unroll
             for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (nb + 1 < n_buffers) load_window(nb + 1, zn);              // flies under the inverse transform
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                              // (3) the A2 products are in LDS
-        cf y[8];
-        if (!second) {
-            const cf* const other = img + kWaveImg;                   // the A2 transform of the same pair
+        for (int nb = 0; nb < n_buffers; ++nb) {
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(1)) {                                        // diagnostic builds: near role idle
+                for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
+                continue;
+            }
+#endif
+            // One piece of work per barrier interval (the far role's transform has six):
+            //   A2 share | window + pass 0 | pass 1 | pass 2 | spectrum + A product | hand-over + requests
+            const int head = (head0 + nb) & (kSlots - 1);
+            cf share[16];                                             // taps [512,1024): last period's spectrum x pmA2
+            {
+                cf vp[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = fft::cadd(z[r], other[rb + 68 * r]);
+                for (int r = 0; r < 16; ++r) share[r] = img[rb + 68 * r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+                spectral_product<kNA, 16>(share, vp, c, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // an opaque copy of the lane index: sixteen loop-invariant 64-bit addresses would otherwise be
+                // hoisted out of the loop, spilled, and reloaded one by one between the loads they feed
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                load_spectra<kNA, 16>(c, pa, lo);                     // for this buffer's A product (interval 5)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                          // barrier 1
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];     // the new block enters the ring
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
+            if (nb + 1 < n_buffers) {                                 // the next buffer's block: needed a period from now
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = xa0 + (nb + 1) * step + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(xa[64 * j], xa[kB + 64 * j]);
+            }
+            WF::run(z, img, t, lane, ArriveAtBarrier());              // barriers 2, 3 from inside
+            __syncthreads();                                          // barrier 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];     // the spectrum stays here for the next period
+            __builtin_amdgcn_wave_barrier();
+            {
+                cf zp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+                spectral_product<kNA, 16>(z, zp, c, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                load_spectra<kNA, 16>(c, pa2, lo);                    // for the next period's A2 share
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                          // barrier 5
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = fft::cadd(z[r], share[r]);   // A product + A2 share
+            __syncthreads();                                          // barrier 6 closes the period
         }
-        __syncthreads();                                              // (4) beside the far role's inverse
-        if (!second) {
-            const cf* const cy = sp.carry + ((size_t)q * kCarrySlots + (head & (kCarrySlots - 1))) * kB;
-            cf park[8];
+        for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // the pipeline's last period
+    } else {
+        // ---- inverse waves: wave 2 + p turns the output spectrum of pair p into samples, one period later
+        const int pr = w - 2;
+        const cf* const hand = lds + (2 + pr) * kWaveImg;
+        cf* const img = lds + (4 + pr) * kWaveImg;                    // the transform's exchanges, then the output swap
+        const cf* const other = lds + (4 + (1 - pr)) * kWaveImg;
+        const cf* const cring = carry + pr * kCarrySlots * kB;
+        using WFi = fft::WaveFFT1024<true>;
+        WFi::Lean t;
+        WFi::load_twiddles(t, tw, lane);
+        for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // first period: nothing to turn yet
+        for (int nb = 1; nb <= n_buffers; ++nb) {
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(1)) {                                        // diagnostic builds: near role idle
+                for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
+                continue;
+            }
+#endif
+            // One piece per barrier interval: hand-over read | pass 0 | pass 1 | pass 2 + far share | swap | stores
+            const int b = nb - 1;                                     // the buffer whose spectrum was handed over last period
+            const int head = (head0 + b) & (kSlots - 1);
+            float* const outb = out + b * step;
+            cf z[16], y[8], park[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) park[j] = cy[lane + 64 * j];
-            WFi::run(z, img, t, lane);
+            for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];    // the forward wave writes the next one in interval 6
+#pragma unroll
+            for (int j = 0; j < 8; ++j) park[j] = cring[(head & (kCarrySlots - 1)) * kB + lane + 64 * j];
+            __syncthreads();                                          // barrier 1
+            WFi::run(z, img, t, lane, ArriveAtBarrier());             // barriers 2, 3 from inside
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
-            if (w == 0) {
+            __syncthreads();                                          // barrier 4
+            // the two pairs of a duo are four neighbouring channels: the waves swap halves through LDS
+            // so that each stores float4 pieces (pair 0 keeps samples lane + 64 j, j < 4, pair 1 j >= 4)
+            if (pr == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[4 + j];
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
             }
-        }
-        __syncthreads();                                              // (5) the swapped halves are in LDS
-        if (!second) {
-            float* const o0 = outb + 4 * (size_t)d;
-            if (w == 0) {
-                const cf* const other = lds + 2 * kWaveImg;
+            __syncthreads();                                          // barrier 5: the swapped halves are in LDS
+            {
+                float* const o0 = outb + 4 * (size_t)d;
+                if (pr == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const cf theirs = other[lane + 64 * j];
-                    *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * j)) = make_float4(y[j].x, y[j].y, theirs.x, theirs.y);
-                }
-            } else {
-                const cf* const other = lds;
+                    for (int j = 0; j < 4; ++j) {
+                        const cf theirs = other[lane + 64 * j];
+                        *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * j)) = make_float4(y[j].x, y[j].y, theirs.x, theirs.y);
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const cf theirs = other[lane + 64 * j];
-                    *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * (4 + j))) = make_float4(theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                    for (int j = 0; j < 4; ++j) {
+                        const cf theirs = other[lane + 64 * j];
+                        *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * (4 + j))) = make_float4(theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                    }
                 }
             }
+            __syncthreads();                                          // barrier 6 closes the period
         }
-        __syncthreads();                                              // closes the buffer
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = zn[r];
     }
+    // every wave is past the last closing barrier: the duo's carry ring goes back to memory
+    for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry_g[i] = carry[i];
 }
 
 // IR bank -> (P, M) spectra of a near (512 taps from offA) and a far (taps from offB) partition.
@@ -1375,7 +1450,7 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
             // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches
             p->order_after_reset(s);
             gab::ConvSplit sp{p->pmA2, p->pmF, p->carry GAB_SPLIT_DEBUG_ARG};
-            gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(2 * gab::kThreads), 0, s>>>(
+            gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
                 d_in, d_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n_buffers);
             int rc = gab::launch_status("conv_split_batch_kernel");
             if (rc) return rc;
