@@ -625,6 +625,18 @@ constexpr int kBatchBarriers = 6;
 constexpr int kBatchThreads = 2 * kThreads;
 constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;      // cf entries (151 KB)
 
+#ifdef GAB_ABLATE
+// diagnostic bit 64: in period 32 of a launch every wave's lane 0 stamps s_memrealtime (100 MHz) —
+// near waves when they ARRIVE at each of the six barriers (slots 0-5) and after the last (6), far waves
+// after each barrier RELEASES them (slots 0-5) and at the period's start (6); slot = [block][wave][8].
+#define GAB_BSTAMP(i)                                                                                     \
+    do {                                                                                                  \
+        if (GAB_SDBG(64) && nb == 32 && lane == 0)                                                        \
+            g_split_stamps[((size_t)blockIdx.x * 8 + w) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+#else
+#define GAB_BSTAMP(i) do {} while (0)
+#endif
 struct ArriveAtBarrier { __device__ __forceinline__ void operator()(int) const { __syncthreads(); } };
 
 __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
@@ -653,6 +665,8 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         using FBi = fft::BlockFFT<kNB, 16, true>;
         typename FB::Mixed twb;
         FB::load_twiddles(twb, tw, ft);
+        // (Measured, not kept: the next buffer's 36 requests spread over three barrier intervals instead of
+        // one burst after the spectral product — the burst's 0.6 us on the chain only moves: 5.75 vs 5.31 us.)
         auto load_window = [&](int nb, cf (&z)[16], float4 (&c)[16]) {
             const int head = (head0 + nb) & (kSlots - 1);
             const int q = 2 * d + (head & 1);
@@ -687,13 +701,23 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
 #endif
             const int head = (head0 + nb) & (kSlots - 1);
             cf* const cp = carry + (head & 1) * kCarrySlots * kB;
+            GAB_BSTAMP(6);
+#ifdef GAB_ABLATE
+            FB::run(zb, far_x, far_y, twb, ft, true, [&](int p) { GAB_BSTAMP(p); });
+#else
             FB::run(zb, far_x, far_y, twb, ft);                       // barriers 1, 2
+#endif
             partner_exchange<kNB, 16, true>(zb, zn, far_x, ft);       // barrier 3
+            GAB_BSTAMP(2);
             spectral_product<kNB, 16>(zb, zn, cb, ft);
             __builtin_amdgcn_sched_barrier(0);
             if (nb + 1 < n_buffers) load_window(nb + 1, zn, cb);      // flies under the inverse transform
             __builtin_amdgcn_sched_barrier(0);
+#ifdef GAB_ABLATE
+            FBi::template run<typename FB::Mixed, 4>(zb, far_y, far_x, twb, ft, true, [&](int p) { GAB_BSTAMP(3 + p); });
+#else
             FBi::template run<typename FB::Mixed, 4>(zb, far_y, far_x, twb, ft);   // barriers 4, 5; only [12..15]
+#endif
             cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;              // block k+1
             cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;              // block k+2
             c1[ft] = zb[12];
@@ -701,6 +725,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             c2[ft] = zb[14];
             c2[ft + kThreads] = zb[15];
             __syncthreads();                                          // barrier 6 closes the period
+            GAB_BSTAMP(5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) zb[r] = zn[r];
         }
@@ -763,6 +788,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
                 load_spectra<kNA, 16>(c, pa, lo);                     // for this buffer's A product (interval 5)
             }
             __builtin_amdgcn_sched_barrier(0);
+            GAB_BSTAMP(0);
             __syncthreads();                                          // barrier 1
 #pragma unroll
             for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
@@ -777,7 +803,12 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) nxt[j] = mk(xa[64 * j], xa[kB + 64 * j]);
             }
+#ifdef GAB_ABLATE
+            WF::run(z, img, t, lane, [&](int i) { GAB_BSTAMP(1 + i); __syncthreads(); });
+#else
             WF::run(z, img, t, lane, ArriveAtBarrier());              // barriers 2, 3 from inside
+#endif
+            GAB_BSTAMP(3);
             __syncthreads();                                          // barrier 4
 #pragma unroll
             for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];     // the spectrum stays here for the next period
@@ -795,10 +826,13 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
                 load_spectra<kNA, 16>(c, pa2, lo);                    // for the next period's A2 share
             }
             __builtin_amdgcn_sched_barrier(0);
+            GAB_BSTAMP(4);
             __syncthreads();                                          // barrier 5
 #pragma unroll
             for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = fft::cadd(z[r], share[r]);   // A product + A2 share
+            GAB_BSTAMP(5);
             __syncthreads();                                          // barrier 6 closes the period
+            GAB_BSTAMP(6);
         }
         for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // the pipeline's last period
     } else {
@@ -828,10 +862,16 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];    // the forward wave writes the next one in interval 6
 #pragma unroll
             for (int j = 0; j < 8; ++j) park[j] = cring[(head & (kCarrySlots - 1)) * kB + lane + 64 * j];
+            GAB_BSTAMP(0);
             __syncthreads();                                          // barrier 1
+#ifdef GAB_ABLATE
+            WFi::run(z, img, t, lane, [&](int i) { GAB_BSTAMP(1 + i); __syncthreads(); });
+#else
             WFi::run(z, img, t, lane, ArriveAtBarrier());             // barriers 2, 3 from inside
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+            GAB_BSTAMP(3);
             __syncthreads();                                          // barrier 4
             // the two pairs of a duo are four neighbouring channels: the waves swap halves through LDS
             // so that each stores float4 pieces (pair 0 keeps samples lane + 64 j, j < 4, pair 1 j >= 4)
@@ -842,6 +882,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
             }
+            GAB_BSTAMP(4);
             __syncthreads();                                          // barrier 5: the swapped halves are in LDS
             {
                 float* const o0 = outb + 4 * (size_t)d;
@@ -859,7 +900,9 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
                     }
                 }
             }
+            GAB_BSTAMP(5);
             __syncthreads();                                          // barrier 6 closes the period
+            GAB_BSTAMP(6);
         }
     }
     // every wave is past the last closing barrier: the duo's carry ring goes back to memory

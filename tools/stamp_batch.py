@@ -1,0 +1,32 @@
+"""Diagnostic build only (GAB_LIB_PATH=.../libgab_hip_ablate.so): barrier timeline of one period (buffer 32 of a
+64-buffer launch) of conv_split_batch_kernel.  Near waves (0-1 forward, 2-3 inverse) stamp their ARRIVAL at each
+of the six barriers (and the release of the last); far waves (4-7) stamp each barrier's RELEASE (and the period's
+start).  Prints, over all 256 workgroups, the median interval lengths and how long each near stage waits."""
+import ctypes, os, sys
+os.environ["GAB_CONV_SPLIT_DEBUG"] = "64"
+sys.path.insert(0, ".")
+import numpy as np, torch
+import gpuaudiobench_amd as gab
+T, B, L, NB = 1024, 512, 4096, 64
+plan = gab.ConvPlan(T, B, L); plan.set_ir(torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda())
+x = torch.from_numpy(np.concatenate([gab.harness.noise(T * B, seed=s) for s in range(NB)])).cuda(); y = torch.empty_like(x)
+a = plan.prepare_batch(x, NB, y)
+for _ in range(150): plan.launch_batch(a)
+torch.cuda.synchronize()
+n = 256 * 8 * 8
+buf = (ctypes.c_ulonglong * n)()
+fn = gab.lib.gab_debug_split_stamps; fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert fn(buf, n) == 0
+st = np.array(buf[:], dtype=np.int64).reshape(256, 8, 8) * 0.01      # us
+far = st[:, 4, :]                       # wave 4: slot 6 = period start, slots 0..5 = release of barriers 1..6
+start = far[:, 6]
+rel = far[:, :6] - start[:, None]
+print("far view: barrier release times after the period's start (us), median over workgroups:")
+print("   " + "  ".join("b%d %.2f" % (i + 1, np.median(rel[:, i])) for i in range(6)))
+iv = np.diff(np.concatenate([np.zeros((256, 1)), rel], axis=1), axis=1)
+print("   interval lengths: " + "  ".join("%.2f" % np.median(iv[:, i]) for i in range(6)) + "   period %.2f" % np.median(rel[:, 5]))
+for wv, name in ((0, "forward (pair 0)"), (1, "forward (pair 1)"), (2, "inverse (pair 0)"), (3, "inverse (pair 1)")):
+    arr = st[:, wv, :6] - start[:, None]
+    wait = rel - arr                   # time the wave spent waiting at each barrier
+    print("%-17s arrival: " % name + "  ".join("%.2f" % np.median(arr[:, i]) for i in range(6)) +
+          "   waits: " + "  ".join("%.2f" % np.median(wait[:, i]) for i in range(6)))
