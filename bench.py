@@ -175,8 +175,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under a launcher (WORLD_SIZE set) the process group is created even for ONE rank, so that a one-GPU
+    # box walks the RCCL path too: communicator, bank broadcast, barrier, all-reduce of the timing.
+    grouped = "WORLD_SIZE" in os.environ
+    backend = None
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -192,9 +198,9 @@ def main():
     from gpuaudiobench_amd import sharding
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ir_dev = sharding.broadcast_ir_bank(L, T_total, rank, world, dev, dist if world > 1 else None)
+    ir_dev = sharding.broadcast_ir_bank(L, T_total, rank, world, dev, dist if grouped else None)
     torch.cuda.synchronize()
-    bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None
+    bcast_ms = (time.perf_counter() - t0) * 1e3 if grouped else None
 
     plan = gab.ConvPlan(T, B, L)
     plan.set_ir(ir_dev)
@@ -218,7 +224,7 @@ def main():
 
     # ---- timed region -------------------------------------------------------------
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -226,14 +232,14 @@ def main():
     run_steps(args.steps)
     e1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     n_buffers = args.steps * NB
     launch_us = e0.elapsed_time(e1) * 1e3 / args.steps       # average launch period, device clock
 
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -283,7 +289,7 @@ def main():
                            "streamed through HBM" % (NB * T * B * 4 >> 20, NB * T * B * 4 >> 20),
             "clock_warm_steps": args.clock_warm_steps,
             "realtime_factor": (world * n_buffers / elapsed) * B / FS,
-            "ir_broadcast_ms": bcast_ms,
+            "ir_broadcast_ms": bcast_ms, "collective_backend": backend,
             "state_bytes": {"spectra": spectra_bytes, "history": history_bytes},
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GAB_")},
         },
@@ -323,7 +329,7 @@ def main():
         result["library_baseline"] = library_baseline(T, B, L)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     if parity is not None and not parity["ok"]:
         sys.stderr.write("bench.py: PARITY CHECK FAILED: %s\n" % json.dumps(parity))

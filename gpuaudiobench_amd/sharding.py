@@ -25,7 +25,7 @@ def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=
     """Returns this rank's slice (tracks x ir_len, contiguous, on `device`) of the
     global conv1d_accel bank.  Rank `src` generates the whole bank."""
     lo, hi = shard_range(rank, world, total_tracks)
-    if world == 1 or dist is None:
+    if dist is None:                # no process group: one rank makes its own bank
         return torch.from_numpy(harness.conv_accel_ir(ir_len, hi - lo, lo, total_tracks)).to(device)
     bank = torch.empty(total_tracks * ir_len, dtype=torch.float32, device=device)
     if rank == src:

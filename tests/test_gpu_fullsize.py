@@ -327,3 +327,24 @@ def test_fdtd_non_cubic_rooms_bit_exact(gab, orc, nx, ny, nz, samples):
     assert np.array_equal(bits(host(plan.pressure()).ravel()), bits(grids[0]))
     assert np.abs(grids[0]).max() > 0
     plan.close()
+
+
+def test_bench_under_a_launcher_walks_the_rccl_path_on_one_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the rank creates the RCCL
+    process group (backend nccl), broadcasts the impulse-response bank through it, meets the barriers and
+    all-reduces the timing — the N > 1 code path with one rank, on the hardware the box has — and the
+    line still carries the in-run parity check."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(root, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--clock-warm-steps", "5",
+                        "--no-side-legs", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "nccl"
+    assert d["config"]["ir_broadcast_ms"] is not None and d["config"]["ir_broadcast_ms"] >= 0
+    assert d["parity_checked"]["ok"] is True and d["value"] > 0
