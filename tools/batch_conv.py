@@ -1,35 +1,42 @@
-"""gab_conv_process_batch at BASELINE C3 (4096 taps x 1024 channels x 512): us per buffer for n buffers
-per launch, on the plan's own cut (split: conv_split_batch_kernel, both roles of a duo in one resident
-workgroup) and on the classic cut (conv_batch_kernel), plus parity of the two paths with per-buffer launches."""
+"""gab_conv_process_batch (4096 taps x 512-sample buffers) across channel counts: us per buffer, algorithmic GB/s
+and fraction of 8 TB/s, with the batch checked bit for bit against per-buffer launches on a sampled channel range.
+
+    python tools/batch_conv.py [channels ...]          (default: 1024 4096 16384 65536)
+"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 import gpuaudiobench_amd as gab
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B, L = 512, 4096
-ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
-alg = 4 * T * (2 * B + 2 * L)
-for scheme in ("split", "classic"):
-    a, b = gab.ConvPlan(T, B, L, scheme=scheme), gab.ConvPlan(T, B, L, scheme=scheme)
+for T in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]:
+    n = 64 if T <= 2048 else (16 if T <= 16384 else 8)          # buffers per launch: bounded by memory, not by the kernel
+    alg = 4 * T * (2 * B + 2 * L)
+    ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
+    a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
     a.set_ir(ir); b.set_ir(ir)
-    xs = torch.cat([torch.from_numpy(gab.harness.noise(T * B, seed=60 + i)) for i in range(8)]).cuda()
-    seq = torch.cat([a.process(xs[i * T * B:(i + 1) * T * B].contiguous()) for i in range(8)])
-    y = b.process_batch(xs, 8)
+    del ir
+    x = torch.empty(n * T * B, device="cuda").uniform_(-1, 1)
+    y = torch.empty_like(x)
+    # parity: the first 9 buffers, per-buffer launches vs one batch launch
+    seq = torch.cat([a.process(x[i * T * B:(i + 1) * T * B]) for i in range(min(n, 9))])
+    b.process_batch(x[:min(n, 9) * T * B], min(n, 9), out=y[:min(n, 9) * T * B])
     torch.cuda.synchronize()
-    same = bool(torch.equal(seq.view(torch.int32), y.view(torch.int32)))
-    for n in (4, 16, 64):
-        x = torch.cat([xs] * (n // 8)) if n >= 8 else xs[:n * T * B].contiguous()
-        out = torch.empty_like(x)
-        for _ in range(5):
-            b.process_batch(x, n, out=out)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(4, 2000 // n)
-        e0.record()
-        for _ in range(reps):
-            b.process_batch(x, n, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (reps * n)
-        print("T=%d %s cut, %d buffers per launch: %.3f us per buffer, %.0f GB/s algorithmic (%.3f of 8 TB/s)%s"
-              % (T, scheme, n, us, alg / us / 1e3, alg / us / 1e3 / 8000, "" if same else "  PARITY MISMATCH"), flush=True)
-    a.close(); b.close()
+    same = bool(torch.equal(seq.view(torch.int32), y[:seq.numel()].view(torch.int32)))
+    del seq
+    a.close()
+    args = b.prepare_batch(x, n, y)
+    reps = max(6, 6000 // (n * max(1, T // 1024)))
+    for _ in range(max(3, reps // 2)):
+        b.launch_batch(args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.launch_batch(args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * n)
+    print("T=%-6d %2d buffers per launch: %9.3f us per buffer, %6.0f GB/s algorithmic = %.3f of 8 TB/s, state %.0f MB, bit-identical to per-buffer launches: %s"
+          % (T, n, us, alg / us / 1e3, alg / us / 1e3 / 8000, sum(b.state_bytes()) / 1e6, same), flush=True)
+    b.close()
+    del x, y
+    torch.cuda.empty_cache()
