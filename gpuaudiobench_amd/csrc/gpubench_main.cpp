@@ -38,6 +38,8 @@ void printHelp() {
     printf("  --fdtdGrid [n]      FDTD3D grid edge including the boundary shell (default: 52)\n");
     printf("  --fdtdSteps [n]     FDTD3D: leapfrog steps per iteration (3 per sample: sets the buffer to ceil(n/3) samples)\n");
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
+    printf("  --convBatch [n]     Conv1D_accel: an iteration is ONE launch over n HBM-resident buffers (throughput mode,\n");
+    printf("                      no per-iteration copies); default: one buffer per iteration with its copies\n");
     printf("  --gpus [n]          Run on n devices, one host thread each: Conv1D_accel as contiguous channel shards of\n");
     printf("                      --nTracks with the impulse-response bank broadcast once over RCCL; others as replicas\n");
     printf("  --print-shards      Print the channel shards --gpus / --nTracks give and exit (no device is touched)\n");
@@ -265,6 +267,11 @@ int main(int argc, char** argv) {
             CPU_THREADS = atoi(argv[++i]);
             if (CPU_THREADS < 0) { printf("Error: --cpu-threads must be >= 0\n"); return 1; }
             g_skip_cpu_golden = CPU_THREADS == 0;
+        }
+        else if (strcmp(argv[i], "--convBatch") == 0) {
+            if (!need("--convBatch")) return 1;
+            CONV_BATCH = atoi(argv[++i]);
+            if (CONV_BATCH < 1) { printf("Error: --convBatch must be >= 1\n"); return 1; }
         }
         else if (strcmp(argv[i], "--convMode") == 0) {
             if (!need("--convMode")) return 1;

@@ -241,6 +241,13 @@ public:
     // bank that was broadcast over RCCL); setupBenchmark() then transforms those instead of uploading
     // its own copy.  The golden still uses the host formula, so validate() cross-checks the bank.
     void shareImpulseResponses(const float* d_rows) { d_shared_ir_ = d_rows; }
+    // Throughput mode (additive; bench.py's `value` through the harness): an iteration is ONE
+    // gab_conv_process_batch launch over n consecutive buffers that are resident in HBM (generated once,
+    // noise seeds 42, 43, ...; no per-iteration copies), history carried from one iteration to the next.
+    // Streaming mode only; validate() checks the first buffer of a batch from reset against the golden.
+    // Defaults to the CONV_BATCH global (--convBatch).
+    void setBatch(int n_buffers) { batch_ = n_buffers > 1 ? n_buffers : 0; }
+    int batch() const { return batch_; }
     int irLength() const { return ir_length_; }
     int fftSize() const { return fft_size_; }
     int overlapSize() const { return overlap_size_; }
@@ -258,6 +265,9 @@ private:
     float* cpu_reference = nullptr;
     gab_conv_plan* plan_ = nullptr;
     const float* d_shared_ir_ = nullptr;
+    int batch_ = 0;
+    float* d_batch_in_ = nullptr;
+    float* d_batch_out_ = nullptr;
     size_t ir_buffer_size;
     size_t ir_buffer_bytes;
     float peak_norm_error_ = 0.0f;

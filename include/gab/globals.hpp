@@ -40,5 +40,7 @@ std::string generateJSONResults(const std::vector<float>& vec, const std::string
 // `extra_members` is the text of one or more `"key": value` members, comma-separated, no trailing comma.
 std::string generateJSONResultsWith(const std::vector<float>& vec, const std::string& benchmarkName,
                                     const std::string& extra_members);
+extern int CONV_BATCH;           // --convBatch    (<=1: one buffer per iteration with its H2D / D2H copies, as the reference;
+                                 //                 n: n HBM-resident buffers per iteration in ONE gab_conv_process_batch launch)
 extern int FDTD_STEPS;           // --fdtdSteps    (<=0: bufferSize samples x 3 steps, as the reference)
 extern int CPU_THREADS;          // --cpu-threads  (<=0: every hardware thread) for the timed CPU golden

@@ -186,3 +186,20 @@ def test_driver_validate_only_and_fdtd_steps():
     assert r.returncode == 0, r.stdout[-2000:]
     assert "30 steps asked for -> 10 samples x 3 steps = 30 steps" in r.stdout
     assert "Validation passed for FDTD3D" in r.stdout and "Running FDTD3D benchmark (" not in r.stdout
+
+
+def test_driver_throughput_mode_reproduces_the_headline_through_the_harness():
+    """gpubench --convBatch 64: an iteration is ONE gab_conv_process_batch launch over 64 HBM-resident
+    buffers (bench.py's `value` path behind the reference's driver); the first buffer of a batch from
+    reset validates against the golden, and the JSON's roofline prices 64 buffers per launch."""
+    r = run_driver("--benchmark", "Conv1D_accel", "--irLength", "4096", "--nTracks", "1024", "--convBatch", "64",
+                   "--nRuns", "150", "--json", "--cpu-threads", "0")
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Validation passed for Conv1D_accel" in r.stdout
+    d = _json_of(r.stdout)
+    assert d["roofline"]["algorithmic_bytes"] == 64 * 4 * 1024 * (2 * 512 + 2 * 4096)
+    assert d["validation"]["passed"] is True and d["validation"]["max_error"] <= 1e-5
+    assert 0.3 < d["roofline"]["device_median_ms"] < 0.6          # 64 buffers in one launch: 0.34 ms warm
+    assert d["roofline"]["frac"] > 0.6
+    r = run_driver("--benchmark", "Conv1D_accel", "--convBatch", "0")
+    assert r.returncode == 1 and "Error: --convBatch must be >= 1" in r.stdout

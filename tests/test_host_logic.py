@@ -198,5 +198,5 @@ def test_driver_shard_arithmetic_and_flags_without_a_gpu():
         r = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
         assert r.returncode == 1 and "Error" in r.stdout, (bad, r.stdout)
     help_text = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=60).stdout
-    for flag in ("--gpus", "--fdtdSteps", "--validate-only", "--cpu-threads", "--print-shards"):
+    for flag in ("--gpus", "--fdtdSteps", "--validate-only", "--cpu-threads", "--print-shards", "--convBatch"):
         assert flag in help_text
