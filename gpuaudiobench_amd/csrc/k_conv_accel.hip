@@ -1057,10 +1057,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_uniform_kernel(
     cf acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = mk(0.0f, 0.0f);
-    const int J = STREAM ? u.J : 1;
+    // (a run-time 1 in stateless mode: as a compile-time constant the loop is peeled and the allocator spills 1 KB)
+    const int J = STREAM ? u.J : (u.J > 0 ? 1 : 0);
     for (int j = 0; j < J; ++j) {
         const unsigned back = j == 0 ? 0u : (unsigned)(B + (j - 1) * u.S);      // how far this window ends before the newest sample
         cf z[16];
+        float zero = 0.0f;                                   // opaque: a literal zero history lets the compiler specialise the
+        asm volatile("" : "+v"(zero));                       // first pass sixteen ways (1 KB of scratch in the stateless form)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = tid + kThreads * r;
@@ -1070,11 +1073,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_uniform_kernel(
             } else if (STREAM) {
                 z[r] = ring[(u.pos + (unsigned)(n - newest) - back) & (unsigned)u.ring_mask];
             } else {
-                z[r] = mk(0.0f, 0.0f);
+                z[r] = mk(zero, zero);
             }
         }
         float4 c[16];
-        load_spectra<kNB, 16>(c, u.pm + ((size_t)j * pairs + q) * kBinsB, tid);
+        {
+            int to = tid;                                    // opaque: keeps sixteen 64-bit addresses out of long-lived registers
+            asm volatile("" : "+v"(to));
+            load_spectra<kNB, 16>(c, u.pm + ((size_t)j * pairs + q) * kBinsB, to);
+        }
         FB::run(z, X, Y, twb, tid);                          // last reads Y
         cf zp[16];
         partner_exchange<kNB, 16, true>(z, zp, X, tid);      // writes X, barrier, reads X
