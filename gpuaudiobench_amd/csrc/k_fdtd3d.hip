@@ -276,25 +276,39 @@ __global__ __launch_bounds__(LX * ROWS) void fdtd_step_lds_kernel(Fields o, Fiel
     // else, so that the step pays ONE memory round trip (they are needed after the barrier only)
     float4 h_pzm = pc4, h_pzp = pc4, h_vzp = pc4;
     float h_vx4 = 0.0f;
+    // The halo rows of the tile (its first row also parks row y0-1, its last row the rows above) are
+    // requested in the same burst: as "load, wait, park" inside their branches each of them was a
+    // further dependent round trip for the edge waves, and a workgroup is as late as its last wave.
+    float4 halo_pm, halo_vy, halo_pp;        // set and used under the same predicates only (no default: a merge copy
+                                             // behind a conditional load costs an s_waitcnt vmcnt(0) in the middle of the burst)
+    const bool need_pm = live && ty == 0 && y > 0;                              // row y0-1
+    const bool need_vy = live && (ty == ROWS - 1 || y == ny - 1);               // vy face y+1 (exists up to ny)
+    const bool need_pp = need_vy && y < ny - 1;                                 // row y+1
     if (live) {
         pc4 = ld4(o.p + pi);
         vy4 = ld4(o.vy + iy);
         vx4 = ld4(o.vx + ix);
         vz4 = ld4(o.vz + iz);
+        if (need_pm) halo_pm = ld4(o.p + pi - nx);
+        if (need_vy) halo_vy = ld4(o.vy + iy + nx);
+        if (need_pp) halo_pp = ld4(o.p + pi + nx);
         if constexpr (HOIST) {
+            // unconditional, with the offset clamped on the first / last plane (the value is not used there):
+            // under `if (z > 0)` the compiler merges the loaded registers with their zero defaults by a copy
+            // placed right behind the load — an s_waitcnt vmcnt(0) in the middle of the burst
             h_vx4 = o.vx[ix + 4];
-            if (z > 0) h_pzm = ld4(o.p + pi - sxy);
-            if (z < nz - 1) h_pzp = ld4(o.p + pi + sxy);
+            h_pzm = ld4(o.p + pi - (z > 0 ? sxy : 0));
+            h_pzp = ld4(o.p + pi + (z < nz - 1 ? sxy : 0));
             h_vzp = ld4(o.vz + iz + sxy);
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);           // every request is out before the first one is waited for
+    if (live) {
         lds4(prow, pc4);
         lds4(vrow, vy4);
-        if (ty == 0 && y > 0) lds4(prow - W, ld4(o.p + pi - nx));                          // row y0-1
-        const bool last_row = ty == ROWS - 1 || y == ny - 1;
-        if (last_row) {
-            lds4(vrow + W, ld4(o.vy + iy + nx));                                           // vy face y+1 (exists up to ny)
-            if (y < ny - 1) lds4(prow + W, ld4(o.p + pi + nx));                            // row y+1
-        }
+        if (need_pm) lds4(prow - W, halo_pm);
+        if (need_vy) lds4(vrow + W, halo_vy);
+        if (need_pp) lds4(prow + W, halo_pp);
     }
     __syncthreads();
     if (!live) return;
