@@ -36,13 +36,26 @@ __global__ __launch_bounds__(kBlock) void scale_vec4_kernel(const float4* __rest
     const size_t stride = (size_t)gridDim.x * kBlock * kUnroll;
     for (size_t base = (size_t)blockIdx.x * kBlock * kUnroll + threadIdx.x; base < n4; base += stride) {
         float4 v[kUnroll];
+        if (base + (size_t)(kUnroll - 1) * kBlock < n4) {
+            // whole rows: unconditional requests (a load under a per-lane condition is followed by a
+            // register merge, i.e. by an s_waitcnt vmcnt(0) BETWEEN the loads: the copy kernel ran 6.2 us
+            // at 128 tracks where the gain kernel, whose multiply hides the merge, ran 3.8)
 #pragma unroll
-        for (int k = 0; k < kUnroll; ++k)
-            if (base + (size_t)k * kBlock < n4) v[k] = in[base + (size_t)k * kBlock];
+            for (int k = 0; k < kUnroll; ++k) v[k] = in[base + (size_t)k * kBlock];
 #pragma unroll
-        for (int k = 0; k < kUnroll; ++k) {
-            if (SCALE) { v[k].x = gain * v[k].x; v[k].y = gain * v[k].y; v[k].z = gain * v[k].z; v[k].w = gain * v[k].w; }
-            if (base + (size_t)k * kBlock < n4) out[base + (size_t)k * kBlock] = v[k];
+            for (int k = 0; k < kUnroll; ++k) {
+                if (SCALE) { v[k].x = gain * v[k].x; v[k].y = gain * v[k].y; v[k].z = gain * v[k].z; v[k].w = gain * v[k].w; }
+                out[base + (size_t)k * kBlock] = v[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k) {
+                if (base + (size_t)k * kBlock < n4) {
+                    float4 u = in[base + (size_t)k * kBlock];
+                    if (SCALE) { u.x = gain * u.x; u.y = gain * u.y; u.z = gain * u.z; u.w = gain * u.w; }
+                    out[base + (size_t)k * kBlock] = u;
+                }
+            }
         }
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < tail)

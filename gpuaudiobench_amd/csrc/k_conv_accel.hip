@@ -1054,6 +1054,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_uniform_kernel(
     const float* const xb = in + (size_t)tb * B;
     const int newest = kNB - B;                    // window positions >= newest are the new block (partition 0)
 
+    if (STREAM) {
+        // The new block enters the ring FIRST (its slot holds the oldest samples, which no window reaches), so
+        // that every window — partition 0's too — is sixteen unconditional loads from one place.  (Round 2 read
+        // partition 0's newest samples from the input buffer under a per-element condition: each such load was
+        // followed by a register merge, i.e. an s_waitcnt vmcnt(0) — sixteen dependent round trips per window.)
+        for (int s = tid; s < B; s += kThreads)
+            ring[(u.pos + (unsigned)s) & (unsigned)u.ring_mask] = mk(xa[s], hasb ? xb[s] : 0.0f);
+        __threadfence_block();                               // the stores are out of this CU's write path ...
+        __syncthreads();                                      // ... before any wave of the workgroup reads them back
+    }
     cf acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = mk(0.0f, 0.0f);
@@ -1067,11 +1077,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_uniform_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = tid + kThreads * r;
-            if (j == 0 && n >= newest) {
+            if (STREAM) {
+                z[r] = ring[(u.pos + (unsigned)(n - newest) - back) & (unsigned)u.ring_mask];
+            } else if (n >= newest) {                        // stateless: the new block over a zero history
                 const int s = n - newest;
                 z[r] = mk(xa[s], hasb ? xb[s] : 0.0f);
-            } else if (STREAM) {
-                z[r] = ring[(u.pos + (unsigned)(n - newest) - back) & (unsigned)u.ring_mask];
             } else {
                 z[r] = mk(zero, zero);
             }
@@ -1091,11 +1101,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_uniform_kernel(
         __syncthreads();                                      // X's readers are done before the next forward writes it
     }
     FBi::run(acc, X, Y, twb, tid);
-    if (STREAM) {
-        // the new block enters the ring (its slot holds the oldest samples, which no window reaches)
-        for (int s = tid; s < B; s += kThreads)
-            ring[(u.pos + (unsigned)s) & (unsigned)u.ring_mask] = mk(xa[s], hasb ? xb[s] : 0.0f);
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = tid + kThreads * r;
