@@ -344,6 +344,8 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
 
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
                                       (4, 512, 1100, 37), (2048, 512, 4096, 3), (12, 512, 4096, 1), (36, 512, 3000, 2),
+                                      (8192, 512, 4096, 2),      # C5's channel count: 2048 workgroups, eight rounds of the device
+
                                       (16, 512, 512, 4), (3, 256, 700, 5)])
 def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
     """gab_conv_process_batch: n buffers in one launch walk the same history as n launches — same
