@@ -334,11 +334,14 @@ def test_bench_under_a_launcher_walks_the_rccl_path_on_one_gpu():
     process group (backend nccl), broadcasts the impulse-response bank through it, meets the barriers and
     all-reduces the timing — the N > 1 code path with one rank, on the hardware the box has — and the
     line still carries the in-run parity check."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(root, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "1", "--steps", "3", "--warmup", "1", "--clock-warm-steps", "5",
                         "--no-side-legs", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, cwd=root, env=env)
