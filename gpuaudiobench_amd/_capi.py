@@ -45,7 +45,7 @@ class FdtdParams(C.Structure):
 
 class BenchConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
-        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet", "modal_mode")]
+        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet", "modal_mode", "conv_batch")]
 
 
 class BenchResult(C.Structure):

@@ -103,6 +103,7 @@ void gab_bench_default_config(gab_bench_config* c) {
     c->conv_mode = GAB_CONV_STREAMING;
     c->quiet = 1;
     c->modal_mode = 0;
+    c->conv_batch = 0;
 }
 
 int gab_bench_count(void) { return static_cast<int>(gab::benchmarkNames().size()); }
@@ -126,6 +127,7 @@ int gab_bench_create(gab_bench** out, const char* name, const gab_bench_config* 
         CONV_STREAMING = (c.conv_mode == GAB_CONV_STREAMING) ? 1 : 0;
         GAB_QUIET = c.quiet != 0;
         MODAL_REAL = c.modal_mode != 0;
+        CONV_BATCH = c.conv_batch;
         auto impl = gab::createBenchmark(name);
         if (!impl) return gab::bad_arg("gab_bench_create: unknown benchmark name");
         auto* b = new gab_bench;

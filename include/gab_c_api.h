@@ -298,6 +298,9 @@ typedef struct {
     int    quiet;           /* suppress the reference's progress printf        */
     int    modal_mode;      /* ModalFilterBank: 0 the CUDA port's placeholder
                                (bench_modal.cu:15-36), 1 the real bank (Metal port) */
+    int    conv_batch;      /* Conv1D_accel: <=1 one buffer per iteration with its copies (the
+                               reference); n: n HBM-resident buffers per iteration in ONE
+                               gab_conv_process_batch launch (throughput mode)           */
 } gab_bench_config;
 
 typedef struct {

@@ -203,3 +203,14 @@ def test_driver_throughput_mode_reproduces_the_headline_through_the_harness():
     assert d["roofline"]["frac"] > 0.6
     r = run_driver("--benchmark", "Conv1D_accel", "--convBatch", "0")
     assert r.returncode == 1 and "Error: --convBatch must be >= 1" in r.stdout
+
+
+def test_harness_conv_batch_config(gab):
+    """gab_bench_config.conv_batch: the throughput mode through the C harness API."""
+    b = gab.Benchmark("Conv1D_accel", n_tracks=64, ir_length=4096, conv_batch=12)
+    b.setup()
+    r = b.run(iterations=5, warmup=1)
+    v, text = b.validate()
+    assert v.status == 0 and v.max_error <= 1e-5, text
+    assert b.algorithmic_bytes() == 12 * 4 * 64 * (2 * 512 + 2 * 4096) and r.gpu_median_ms > 0
+    b.close()
