@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--clock-warm-steps", type=int, default=CLOCK_WARM_STEPS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="only the timed region (profiling runs)")
+    ap.add_argument("--batch-sizes", action="store_true",
+                    help="also time 8 / 16 / 32 buffers per launch (off by default: those launches carry the headline "
+                         "kernel's name and would mix into a profiler's per-kernel average of the 64-buffer launches)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -251,7 +254,7 @@ def main():
     alg = algorithmic_bytes(T, B, L)
     side = {}
     if not args.no_side_legs:
-        side = side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch)
+        side = side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, args.batch_sizes)
 
     traffic = None
     pmc_file = os.path.join(ROOT, TRAFFIC_SOURCE)
@@ -383,7 +386,7 @@ def library_baseline(T, B, L):
         return {"error": repr(e)[:300]}
 
 
-def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch):
+def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, batch_sizes=False):
     """Rates that are NOT `value`, each with a fixed iteration count (independent of --steps)."""
     NB = len(host_in)
     alg = algorithmic_bytes(T, B, L)
@@ -411,7 +414,7 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch):
 
     # ---- batch size: how the per-launch cost (first window, drain, boundary) amortises
     sizes = {}
-    for nb in (8, 16, 32):
+    for nb in ((8, 16, 32) if batch_sizes else ()):
         x = xb[:nb * T * B]
         y = torch.empty_like(x)
         a = plan.prepare_batch(x, nb, y)
@@ -426,7 +429,8 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch):
         torch.cuda.synchronize()
         us = eb0.elapsed_time(eb1) * 1e3 / (reps * nb)
         sizes[str(nb)] = {"us_per_buffer": us, "frac": alg / us / 1e3 / HBM_PEAK_GBS, "launches": reps}
-    res["batch_buffers_per_launch"] = sizes
+    if batch_sizes:
+        res["batch_buffers_per_launch"] = sizes
     plan.reset()
 
     # ---- p50 round trip: pinned host -> HBM -> kernel -> HBM -> pinned host, one buffer in flight
