@@ -7,10 +7,11 @@ TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-legs"
+DRIVER="python3 bench.py --steps 20 --warmup 5"                                  # the driver's command, as it is
+BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-legs"  # the same launches without the CPU legs (PMC passes)
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line_steps20_warmup5.json 2> $OUT/bench.err
 echo "untraced bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- $BENCH > $OUT/bench_line_under_rocprof.json 2> $OUT/bench_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- $DRIVER > $OUT/bench_line_under_rocprof.json 2> $OUT/bench_rocprof.err
 echo "trace done"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"; do
   N=$(echo $C | tr ' ' '_')
