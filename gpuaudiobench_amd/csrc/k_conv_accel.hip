@@ -663,7 +663,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         const int ft = tid - kThreads;
         using FB = fft::BlockFFT<kNB, 16, false>;
         using FBi = fft::BlockFFT<kNB, 16, true>;
-        typename FB::Mixed twb;
+        typename FB::Twiddles twb;                                  // every pass's powers stay in registers
         FB::load_twiddles(twb, tw, ft);
         // (Measured, not kept: the next buffer's 36 requests spread over three barrier intervals instead of
         // one burst after the spectral product — the burst's 0.6 us on the chain only moves: 5.75 vs 5.31 us.)
@@ -714,9 +714,9 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             if (nb + 1 < n_buffers) load_window(nb + 1, zn, cb);      // flies under the inverse transform
             __builtin_amdgcn_sched_barrier(0);
 #ifdef GAB_ABLATE
-            FBi::template run<typename FB::Mixed, 4>(zb, far_y, far_x, twb, ft, true, [&](int p) { GAB_BSTAMP(3 + p); });
+            FBi::template run<typename FB::Twiddles, 4>(zb, far_y, far_x, twb, ft, true, [&](int p) { GAB_BSTAMP(3 + p); });
 #else
-            FBi::template run<typename FB::Mixed, 4>(zb, far_y, far_x, twb, ft);   // barriers 4, 5; only [12..15]
+            FBi::template run<typename FB::Twiddles, 4>(zb, far_y, far_x, twb, ft);   // barriers 4, 5; only [12..15]
 #endif
             cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;              // block k+1
             cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;              // block k+2
