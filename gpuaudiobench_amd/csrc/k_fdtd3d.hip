@@ -501,6 +501,295 @@ __global__ __launch_bounds__(NT) void fdtd_sample_tile_kernel(
     }
 }
 
+// ---- the whole room resident in LDS: ONE launch per buffer ------------------------------------------------
+// 128^3 cells with their three face arrays are 33.75 MB; the chip has 256 x 160 KB = 40 MB of LDS.  The room is
+// cut into blocks of nx x BY x BZ cells, one workgroup (= one CU) each, which keeps its block's p, vx, vy, vz in
+// registers (a thread owns the same cells for the whole launch) and in LDS (where its neighbours inside the
+// block read them) for every step of the buffer; only the block's four pressure faces cross to the
+// neighbouring workgroups, once per step, through memory.  No field touches HBM between the first step of a
+// buffer and its last: a step costs LDS traffic and one neighbour hand-off instead of 67 MB through the
+// memory system and a kernel boundary.
+//
+// A step is the reference's two phases (velocity kernel, pressure kernel: cuda/bench_fdtd3d.cu:14-98) done in
+// place — the fused kernels above compute the same values (they recompute the high faces instead of reading
+// them), so the result is bit-identical to them and to the oracle:
+//   V: every low face from the old pressures: own p in registers, p(x-1), p(y-1), p(z-1) from LDS; the new
+//      faces go to LDS.  The block also keeps its two HIGH ghost faces (vy at y0+BY, vz at z0+BZ — its
+//      neighbours' low faces) and updates them itself with the same operation on the same operands, so
+//      velocities never cross workgroups;
+//   P: pressure from the new faces: own in registers, vx(x+1), vy(y+1), vz(z+1) from LDS; the receiver tap and
+//      the next sample's source add ride on the step that closes a sample, as in the fused kernels;
+//   X: the block's four boundary pressure faces are stored write-through (sc1), the workgroup's flag is
+//      raised (the step's number), the four neighbours' flags are polled, their faces loaded (sc1) into the
+//      ghost layers.  This is the hand-off form MI355X_MICROARCH.md lists as measured-valid on gfx950 (payload
+//      and flag sc1 / agent-scope, every storing wave drained and behind the workgroup's barrier before the
+//      flag, a workgroup barrier between the poll and every load, whole 128-byte lines per store instruction):
+//      no cache-wide fence, and nothing depends on where a workgroup runs.  The exchange buffers alternate
+//      with the step's parity; a neighbour cannot be more than one step apart.
+// Every workgroup must be resident at once: the grid is at most one workgroup per CU (158 KB of LDS each), and
+// every spin is bounded — on a timeout the kernel sets a word the host turns into an error.
+struct ResidentGeom {
+    int by, bz;            // block extent in y and z (cells); x is the whole row
+    int gy, gz;            // blocks along y and z
+    int nq;                // float4 quads per row (nx / 4)
+    int rows;              // rows per block = by * bz
+    int fr;                // rows reserved per exchanged face = max(by, bz)
+};
+
+constexpr int kResThreads = 1024;
+constexpr int kResRowSlots = kResThreads / 32;      // a row of up to 128 cells = 32 lanes x float4
+constexpr int kResRowDwords = 256;                  // one exchanged row: 128 granules {pressure, tag}
+constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling before giving up
+#ifdef GAB_ABLATE
+__device__ int g_res_ablate = 0;                    // diagnostic builds: 1 = no exchange between workgroups (wrong results)
+#endif
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 fnma4(float c, f4 a, f4 b, f4 acc) {      // acc - c * (a - b), one rounding per step
+    return (f4){__builtin_fmaf(-c, __fsub_rn(a.x, b.x), acc.x), __builtin_fmaf(-c, __fsub_rn(a.y, b.y), acc.y),
+                __builtin_fmaf(-c, __fsub_rn(a.z, b.z), acc.z), __builtin_fmaf(-c, __fsub_rn(a.w, b.w), acc.w)};
+}
+
+// One exchanged quad = four granules {pressure bits, tag}, each 8 bytes written by one store; the two 16-byte
+// stores of a row land in the row's two 512-byte halves, so every store instruction writes whole lines.
+__device__ __forceinline__ void publish_quad(unsigned* row, f4 p, unsigned tag) {
+    const u4 a = {__float_as_uint(p.x), tag, __float_as_uint(p.y), tag};
+    const u4 b = {__float_as_uint(p.z), tag, __float_as_uint(p.w), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:512 sc1"
+                 ::"v"(row), "v"(a), "v"(b) : "memory");
+}
+// Both ghost quads of a thread in one burst (a row that needs only one, or none, reads its own slot for the
+// other): four loads in flight, one wait.
+__device__ __forceinline__ void fetch_quads(const unsigned* ry, const unsigned* rz, u4& y0, u4& y1, u4& z0, u4& z1) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:512 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:512 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(y0), "=&v"(y1), "=&v"(z0), "=&v"(z1) : "v"(ry), "v"(rz) : "memory");
+}
+__device__ __forceinline__ unsigned peek_sc1(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int RPT>      // rows per thread slot: ceil(rows / 32)
+__global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
+    Fields f, Grid g, ResidentGeom rg, float c1, float c2, float damp, size_t src, size_t rcv,
+    const float* __restrict__ inj, float* __restrict__ strip, int first_sample, int n_samples, int steps_per_sample,
+    unsigned* __restrict__ xbuf, unsigned tag_base, unsigned* __restrict__ timeout_word) {
+    extern __shared__ float lds[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, px = g.px;
+    const int by = rg.by, bz = rg.bz;
+    const int wg = blockIdx.x;
+    const int bj = wg % rg.gy, bk = wg / rg.gy;
+    const int y0 = bj * by, z0 = bk * bz;
+    const bool has_ym = bj > 0, has_yp = bj + 1 < rg.gy, has_zm = bk > 0, has_zp = bk + 1 < rg.gz;
+    // LDS images, [row = lz * by + ly][nx] each: what a thread's neighbours inside the block read
+    float* const sp = lds;
+    float* const svy = sp + rg.rows * nx;
+    float* const svz = svy + rg.rows * nx;
+
+    const int tid = threadIdx.x;
+    const int xq = tid & 31;                                           // quad within the row
+    const int slot = tid >> 5;
+    const int x0 = 4 * xq;
+    const size_t sxy = (size_t)nx * ny;
+    // exchange rows (dword offsets into xbuf, one parity): workgroup w, face c (0: y-, 1: y+, 2: z-, 3: z+), row i
+    const int wg_dwords = 4 * rg.fr * kResRowDwords;
+    const int parity_dwords = (int)gridDim.x * wg_dwords;
+    auto xrow = [&](int w, int face, int i) { return (w * 4 + face) * rg.fr * kResRowDwords + i * kResRowDwords + 4 * xq; };
+
+    // ---- the thread's cells: row slot + 32 k, k < RPT.  Per row: the four field quads, one ghost pressure
+    // quad per direction (a row is the block's first OR last in a direction: blocks are at least 2 x 2) and,
+    // for a last row, the neighbour's low face above it, which this thread advances itself.  What kind of row
+    // it is sits in one word of bits; the exchange rows are dword offsets into xbuf (-1: none).
+    enum : unsigned {
+        kOn = 1u, kHasYm = 2u, kHasZm = 4u, kHasYp = 8u, kHasZp = 16u,       // the row exists; it has a neighbour row INSIDE the block
+        kFirstY = 32u, kFirstZ = 64u, kLastY = 128u, kLastZ = 256u,           // a neighbour block supplies / wants this row
+        kM0 = 512u, kM12 = 1024u, kM3 = 2048u,                                // which cells of the quad are interior cells of the room
+        kRcvShift = 12, kSrcShift = 15                                        // 1 + j of the receiver / source cell (0: not here)
+    };
+    f4 p4[RPT], vx4[RPT], vy4[RPT], vz4[RPT], gpy[RPT], gpz[RPT], gfy[RPT], gfz[RPT];
+    int o_own[RPT], pub_y[RPT], pub_z[RPT];
+    unsigned kind[RPT];
+    const int up_y = 3 * rg.fr * kResRowDwords;                        // from my y+ row to the next block's y- row (and back: minus)
+    const int up_z = (4 * rg.gy - 1) * rg.fr * kResRowDwords;          // from my z+ row to the next plane of blocks' z- row
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = slot + kResRowSlots * k;
+        const int ly = r % by, lz = r / by;
+        const int y = y0 + ly, z = z0 + lz;
+        const bool on = xq < rg.nq && r < rg.rows && y < ny && z < nz;
+        const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
+        o_own[k] = r * nx + x0;
+        const bool first_y = on && ly == 0 && has_ym, last_y = on && ly == by - 1 && has_yp;
+        const bool first_z = on && lz == 0 && has_zm, last_z = on && lz == bz - 1 && has_zp;
+        pub_y[k] = first_y ? xrow(wg, 0, lz) : last_y ? xrow(wg, 1, lz) : -1;
+        pub_z[k] = first_z ? xrow(wg, 2, ly) : last_z ? xrow(wg, 3, ly) : -1;
+        const bool row_interior = y > 0 && y < ny - 1 && z > 0 && z < nz - 1;
+        unsigned kd = (on ? kOn : 0u) | (ly > 0 ? kHasYm : 0u) | (lz > 0 ? kHasZm : 0u) | (ly + 1 < by ? kHasYp : 0u) |
+                      (lz + 1 < bz ? kHasZp : 0u) | (first_y ? kFirstY : 0u) | (first_z ? kFirstZ : 0u) |
+                      (last_y ? kLastY : 0u) | (last_z ? kLastZ : 0u) | (row_interior && x0 > 0 ? kM0 : 0u) |
+                      (row_interior ? kM12 : 0u) | (row_interior && x0 + 4 < nx ? kM3 : 0u);
+        p4[k] = vx4[k] = vy4[k] = vz4[k] = gpy[k] = gpz[k] = gfy[k] = gfz[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            if (rcv >= pi && rcv < pi + 4) kd |= (unsigned)(rcv - pi + 1) << kRcvShift;
+            if (src >= pi && src < pi + 4) kd |= (unsigned)(src - pi + 1) << kSrcShift;
+            p4[k] = *reinterpret_cast<const f4*>(f.p + pi);
+            vx4[k] = *reinterpret_cast<const f4*>(f.vx + ((size_t)z * ny + y) * px + x0);
+            vy4[k] = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0);
+            vz4[k] = *reinterpret_cast<const f4*>(f.vz + pi);
+            if (first_y) gpy[k] = *reinterpret_cast<const f4*>(f.p + pi - nx);
+            if (last_y) {
+                gpy[k] = *reinterpret_cast<const f4*>(f.p + pi + nx);
+                gfy[k] = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y + 1) * nx + x0);
+            }
+            if (first_z) gpz[k] = *reinterpret_cast<const f4*>(f.p + pi - sxy);
+            if (last_z) {
+                gpz[k] = *reinterpret_cast<const f4*>(f.p + pi + sxy);
+                gfz[k] = *reinterpret_cast<const f4*>(f.vz + pi + sxy);
+            }
+            *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
+        }
+        kind[k] = kd;
+    }
+    __syncthreads();
+
+    const int row_y = nx, row_z = by * nx;                              // LDS strides
+    unsigned tag = tag_base;
+    bool dead = false;                                                  // a neighbour never arrived: stop waiting for good
+    const int last = first_sample + n_samples;
+    const unsigned total_steps = (unsigned)n_samples * (unsigned)steps_per_sample;
+    unsigned step = 0;
+    for (int smp = first_sample; smp < last; ++smp) {
+        for (int st = 0; st < steps_per_sample; ++st, ++step) {
+            const bool closes = st == steps_per_sample - 1;
+            ++tag;
+            // ---- V: the low faces from the old pressures.  A row with no neighbour in a direction (the room's
+            // first row or plane, the row's first cell) reads its OWN pressure there: the difference is +0,
+            // -c1 * +0 is -0 for c1 > 0 (checked by the host), and f + -0 = f for every f — the face keeps its
+            // bits without a branch.
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                unsigned kd = kind[k];
+                asm volatile("" : "+v"(kd));                        // re-derive the row's predicates here, not in 80 hoisted SGPRs
+                const f4 pc = p4[k];
+                float pl = __shfl_up(pc.w, 1);                          // the cell before the quad: the previous lane's last
+                pl = x0 > 0 ? pl : pc.x;
+                if (!(kd & kOn)) continue;
+                f4 pym = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasYm) ? row_y : 0));
+                f4 pzm = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasZm) ? row_z : 0));
+                if (kd & kFirstY) pym = gpy[k];
+                if (kd & kFirstZ) pzm = gpz[k];
+                vx4[k] = fnma4(c1, pc, (f4){pl, pc.x, pc.y, pc.z}, vx4[k]);
+                vy4[k] = fnma4(c1, pc, pym, vy4[k]);
+                vz4[k] = fnma4(c1, pc, pzm, vz4[k]);
+                *reinterpret_cast<f4*>(svy + o_own[k]) = vy4[k];
+                *reinterpret_cast<f4*>(svz + o_own[k]) = vz4[k];
+                // the neighbour's low faces above the block's last row / plane: same operation, same operands
+                if (kd & kLastY) gfy[k] = fnma4(c1, gpy[k], pc, gfy[k]);
+                if (kd & kLastZ) gfz[k] = fnma4(c1, gpz[k], pc, gfz[k]);
+            }
+            __syncthreads();
+            // ---- P: pressure from the new faces; boundary quads go out write-through as they are made
+            unsigned* const xb = xbuf + (step & 1) * parity_dwords;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                unsigned kd = kind[k];
+                asm volatile("" : "+v"(kd));                        // re-derive the row's predicates here, not in 80 hoisted SGPRs
+                const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
+                if (!(kd & kOn)) continue;
+                f4 hy = *reinterpret_cast<const f4*>(svy + o_own[k] + ((kd & kHasYp) ? row_y : 0));
+                f4 hz = *reinterpret_cast<const f4*>(svz + o_own[k] + ((kd & kHasZp) ? row_z : 0));
+                if (kd & kLastY) hy = gfy[k];
+                if (kd & kLastZ) hz = gfz[k];
+                const f4 pc = p4[k], fx = vx4[k], fy = vy4[k], fz = vz4[k];
+                const float fxh[4] = {fx.y, fx.z, fx.w, fxn};
+                const float fxl[4] = {fx.x, fx.y, fx.z, fx.w};
+                const float hyv[4] = {hy.x, hy.y, hy.z, hy.w}, fyv[4] = {fy.x, fy.y, fy.z, fy.w};
+                const float hzv[4] = {hz.x, hz.y, hz.z, hz.w}, fzv[4] = {fz.x, fz.y, fz.z, fz.w};
+                const float pcv[4] = {pc.x, pc.y, pc.z, pc.w};
+                const bool mj[4] = {(kd & kM0) != 0, (kd & kM12) != 0, (kd & kM12) != 0, (kd & kM3) != 0};
+                float pv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float div = __fadd_rn(__fadd_rn(__fsub_rn(fxh[j], fxl[j]), __fsub_rn(hyv[j], fyv[j])),
+                                                __fsub_rn(hzv[j], fzv[j]));
+                    const float pin = __builtin_fmaf(-c2, div, pcv[j]);
+                    const float pd = __fmul_rn(pcv[j], damp);
+                    pv[j] = mj[j] ? pin : pd;
+                }
+                if (closes && (kd >> kRcvShift) != 0) {                 // the receiver's or the source's quad (two lanes of the room)
+                    const int jr = (int)((kd >> kRcvShift) & 7u) - 1, js = (int)((kd >> kSrcShift) & 7u) - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j == jr) strip[smp] = __fmul_rn(pv[j], 0.1f);                       // FDTD3D_OUTPUT_SCALE
+                        if (j == js && smp + 1 < last) pv[j] = __fadd_rn(pv[j], inj[smp + 1]);
+                    }
+                }
+                p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
+                *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
+                if (pub_y[k] >= 0) publish_quad(xb + pub_y[k], p4[k], tag);
+                if (pub_z[k] >= 0) publish_quad(xb + pub_z[k], p4[k], tag);
+            }
+            // ---- X: the neighbours' boundary quads, straight into the registers of the thread that uses
+            // them; the granules' tags say when they are this step's (no flag, no fence: guide R2)
+            if (step + 1 < total_steps) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    unsigned kd = kind[k];
+                asm volatile("" : "+v"(kd));                        // re-derive the row's predicates here, not in 80 hoisted SGPRs
+                    const bool need_y = pub_y[k] >= 0, need_z = pub_z[k] >= 0;
+                    if (!__any(need_y || need_z)) continue;            // the whole wave is interior
+#ifdef GAB_ABLATE
+                    if (g_res_ablate & 1) continue;
+#endif
+                    const int get_y = pub_y[k] + ((kd & kFirstY) ? -up_y : up_y);
+                    const int get_z = pub_z[k] + ((kd & kFirstZ) ? -up_z : up_z);
+                    const unsigned* const ry = xb + (need_y ? get_y : need_z ? get_z : 0);
+                    const unsigned* const rz = xb + (need_z ? get_z : need_y ? get_y : 0);
+                    bool ok = dead || !(need_y || need_z);
+                    unsigned spins = 0;
+                    while (!__all(ok)) {
+                        u4 a0, a1, b0, b1;
+                        fetch_quads(ry, rz, a0, a1, b0, b1);
+                        if (!ok) {
+                            const bool oky = a0.y == tag && a0.w == tag && a1.y == tag && a1.w == tag;
+                            const bool okz = b0.y == tag && b0.w == tag && b1.y == tag && b1.w == tag;
+                            if (oky && okz) {
+                                ok = true;
+                                if (need_y) gpy[k] = (f4){__uint_as_float(a0.x), __uint_as_float(a0.z), __uint_as_float(a1.x), __uint_as_float(a1.z)};
+                                if (need_z) gpz[k] = (f4){__uint_as_float(b0.x), __uint_as_float(b0.z), __uint_as_float(b1.x), __uint_as_float(b1.z)};
+                            } else if ((++spins & 1023u) == 0) {       // a long wait: has anyone given up? is it time to?
+                                if (spins > kResSpinLimit)
+                                    __hip_atomic_store(timeout_word, 1u + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (spins > kResSpinLimit || peek_sc1(timeout_word) != 0) ok = dead = true;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- the block's fields go back to memory (the room's last faces never moved: they are still there)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        if (!(kind[k] & kOn)) continue;
+        const int r = slot + kResRowSlots * k;
+        const int y = y0 + r % by, z = z0 + r / by;
+        const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
+        *reinterpret_cast<f4*>(f.p + pi) = p4[k];
+        *reinterpret_cast<f4*>(f.vx + ((size_t)z * ny + y) * px + x0) = vx4[k];
+        *reinterpret_cast<f4*>(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0) = vy4[k];
+        *reinterpret_cast<f4*>(f.vz + pi) = vz4[k];
+    }
+}
+
 }  // namespace
 }  // namespace gab
 
@@ -535,6 +824,15 @@ struct gab_fdtd_plan {
     bool use_graphs = true;
     bool lds_tiles = true;    // rows wide enough to fill a 32-lane row of the LDS-halo kernel (GAB_FDTD_LDS=0: off)
     bool sample_tiles = true; // small rooms: one launch per sample, S steps in a tile (GAB_FDTD_TILE=0: off)
+    // the room resident in LDS for a whole buffer (fdtd_resident_kernel): geometry, exchange buffers, flags
+    bool resident = true;
+    gab::ResidentGeom rgeom{};
+    int res_rpt = 0;                    // rows per thread slot (0: the grid does not take the resident kernel)
+    size_t res_lds_bytes = 0;
+    unsigned* res_xbuf = nullptr;       // [2 parities][workgroups][4 faces][fr rows][128 granules {pressure, tag}] + the timeout word
+    size_t res_xbuf_dwords = 0;
+    unsigned res_tag = 0;               // steps the resident kernel has run on this plan: the exchange tags go on from here
+    unsigned* res_timeout_host = nullptr;   // pinned copy of the timeout word, checked by the next call
     hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
     std::vector<std::pair<FdtdGraphKey, hipGraphExec_t>> graphs;   // small LRU, newest last
 };
@@ -589,6 +887,37 @@ gab::Fields virtual_base(const gab::Fields& real, const gab_fdtd_plan& pl) {
     return v;
 }
 
+// Blocks of nx x by x bz cells, one workgroup (one CU) each: the most workgroups the device can hold at once
+// whose LDS image fits, at most 64 rows per block (two per thread slot).
+void choose_resident_geometry(gab_fdtd_plan* f) {
+    const gab_fdtd_params& P = f->P;
+    f->res_rpt = 0;
+    if (f->z_begin != 0 || f->z_end != P.nz || (P.nx & 3) || P.nx > 128 || P.nx < 8) return;
+    if (!(P.dt_over_rho_dx > 0.0f)) return;                      // the kernel's branch-free boundary faces need -c1 * 0 = -0
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return;
+    const int lds_max = 160 * 1024;                              // gfx950: 160 KB of LDS per CU (and per workgroup)
+    long best_w = 0, best_surface = 0;
+    for (int bz = 2; bz <= 32; ++bz)
+        for (int by = 2; by <= 32; ++by) {
+            const int rows = by * bz;
+            if (rows > 2 * gab::kResRowSlots) continue;
+            const long gy = (P.ny + by - 1) / by, gz = (P.nz + bz - 1) / bz, w = gy * gz;
+            if (w > cus || w < 2) continue;
+            const size_t floats = (size_t)3 * rows * P.nx;                  // p, vy, vz images
+            if (floats * sizeof(float) + 64 > (size_t)lds_max) continue;
+            const long surface = by + bz;                       // exchanged rows per block ~ 2 (by + bz)
+            if (w > best_w || (w == best_w && surface < best_surface)) {
+                best_w = w;
+                best_surface = surface;
+                f->rgeom = gab::ResidentGeom{by, bz, (int)gy, (int)gz, P.nx / 4, rows, by > bz ? by : bz};
+                f->res_rpt = (rows + gab::kResRowSlots - 1) / gab::kResRowSlots;
+                f->res_lds_bytes = floats * sizeof(float);
+            }
+        }
+}
+
 int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin, int z_end, const char* who) {
     if (!out || !params) return gab::bad_arg((std::string(who) + ": null pointer").c_str());
     if (int rc = gab::refuse_unsupported_runtime_mode(who)) return rc;
@@ -607,6 +936,11 @@ int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin,
     f->z_begin = z_begin;
     f->z_end = z_end;
 #ifdef GAB_ABLATE       // diagnostic builds: pick a kernel form by hand (every form is bit-identical)
+    if (const char* v = getenv("GAB_FDTD_RESIDENT")) f->resident = atoi(v) != 0;
+    if (const char* v = getenv("GAB_FDTD_RES_ABLATE")) {
+        const int a = atoi(v);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gab::g_res_ablate), &a, sizeof(int));
+    }
     if (const char* v = getenv("GAB_FDTD_GRAPH")) f->use_graphs = atoi(v) != 0;
     if (const char* v = getenv("GAB_FDTD_LDS")) f->lds_tiles = atoi(v) != 0;
     if (const char* v = getenv("GAB_FDTD_TILE")) f->sample_tiles = atoi(v) != 0;
@@ -625,6 +959,7 @@ int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin,
     }
     f->cur = virtual_base(f->cur_real, *f);
     f->nxt = virtual_base(f->nxt_real, *f);
+    choose_resident_geometry(f);
     *out = f;
     int rc = gab_fdtd_reset(f, nullptr);
     if (rc) return rc;
@@ -745,6 +1080,8 @@ int gab_fdtd_destroy(gab_fdtd_plan* f) {
     free_fields(f->nxt_real);
     if (f->inj) (void)hipFree(f->inj);
     if (f->strip) (void)hipFree(f->strip);
+    if (f->res_xbuf) (void)hipFree(f->res_xbuf);
+    if (f->res_timeout_host) (void)hipHostFree(f->res_timeout_host);
     free_track_positions(f);
     delete f;
     return GAB_OK;
@@ -780,6 +1117,31 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         // rooms up to 56 cells wide (where one step is shorter than a kernel boundary) take one
         // launch per SAMPLE: three steps inside a tile (fdtd_sample_tile_kernel).  Measured per step:
         // 20^3 1.98 vs 3.8 us, 32^3 2.11 vs 3.7, 52^3 3.49 vs 4.2, 56^3 3.59; at 64^3 the one-step chain wins
+        // a previous resident launch that gave up waiting for a neighbour workgroup left its word here
+        if (f->res_timeout_host && *f->res_timeout_host) {
+            const unsigned at = *f->res_timeout_host;
+            *f->res_timeout_host = 0;
+            f->resident = false;                                     // the step kernels from now on
+            gab::set_last_error("gab_fdtd_process: the LDS-resident kernel of the PREVIOUS call timed out at step " +
+                                std::to_string(at - 1) + " waiting for a neighbour workgroup (device shared with other "
+                                "work?); the plan's fields are undefined, reset it");
+            return GAB_ERR_RUNTIME;
+        }
+        // (not inside a caller's stream capture: the exchange tags are a launch argument that a replay would freeze)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        const bool resident = f->resident && f->res_rpt > 0 && !f->pos_tracks && cap == hipStreamCaptureStatusNone;
+        if (resident && !f->res_xbuf) {
+            const size_t wgs = (size_t)f->rgeom.gy * f->rgeom.gz;
+            f->res_xbuf_dwords = (size_t)2 * wgs * 4 * f->rgeom.fr * gab::kResRowDwords;
+            GAB_HIP_CHECK(hipMalloc(&f->res_xbuf, sizeof(unsigned) * (f->res_xbuf_dwords + 4)));
+            GAB_HIP_CHECK(hipMemsetAsync(f->res_xbuf, 0, sizeof(unsigned) * (f->res_xbuf_dwords + 4), s));   // tag 0 = never written
+            GAB_HIP_CHECK(hipHostMalloc(&f->res_timeout_host, sizeof(unsigned), hipHostMallocDefault));
+            *f->res_timeout_host = 0;
+            const void* fn = f->res_rpt == 1 ? reinterpret_cast<const void*>(gab::fdtd_resident_kernel<1>)
+                                             : reinterpret_cast<const void*>(gab::fdtd_resident_kernel<2>);
+            GAB_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->res_lds_bytes));
+        }
         const bool by_sample = f->sample_tiles && !f->pos_tracks && P.steps_per_sample == 3 && f->z_begin == 0 &&
                                f->z_end == P.nz && P.nx <= 56 && P.ny <= 56 && P.nz <= 56;
         // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
@@ -807,6 +1169,25 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             // the first sample's source goes straight into the current pressure grid; later
             // ones are folded into the step that precedes them
             gab::fdtd_add_source_kernel<<<1, 64, 0, q>>>(cur.p, src, f->inj, first_sample);
+            if (resident) {
+                // the whole buffer in ONE launch, the room resident in LDS (fields updated in place in `cur`)
+                const gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, 0};
+                const size_t rcv = P.receiver_z * sxy + (size_t)P.receiver_y * P.nx + P.receiver_x;
+                const unsigned wgs = (unsigned)(f->rgeom.gy * f->rgeom.gz);
+                unsigned* const tmo = f->res_xbuf + f->res_xbuf_dwords;
+#define GAB_RESIDENT_LAUNCH(RPT)                                                                                   \
+    gab::fdtd_resident_kernel<RPT><<<dim3(wgs), dim3(gab::kResThreads), f->res_lds_bytes, q>>>(                    \
+        cur, g, f->rgeom, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, 1.0f - P.absorption_coeff, src, rcv, f->inj, f->strip, \
+        first_sample, n_samples, P.steps_per_sample, f->res_xbuf, f->res_tag, tmo)
+                if (f->res_rpt == 1) GAB_RESIDENT_LAUNCH(1); else GAB_RESIDENT_LAUNCH(2);
+#undef GAB_RESIDENT_LAUNCH
+                f->res_tag += (unsigned)n_samples * (unsigned)P.steps_per_sample;
+                GAB_HIP_CHECK(hipMemcpyAsync(f->res_timeout_host, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, q));
+                dim3 bgrid((n_samples + 127) / 128, tracks);
+                gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
+                                                                n_samples);
+                return;
+            }
             if (by_sample) {
                 constexpr int TY = 4, TZ = 4, NT = 576;             // 56 x (4 + 6) columns fit 576 threads
                 const gab::Grid g{P.nx, P.ny, P.nz, P.nx + 4, 0};
@@ -838,10 +1219,8 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
             gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
                                                             n_samples);
         };
-        const long swaps = (long)n_samples * (by_sample ? 1 : P.steps_per_sample);
+        const long swaps = resident ? 0 : (long)n_samples * (by_sample ? 1 : P.steps_per_sample);
         const long launches = 3L + swaps;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(s, &cap);
         bool replayed = false;
         if (f->use_graphs && launches >= 24 && cap == hipStreamCaptureStatusNone) {
             const FdtdGraphKey key{d_in, d_out, tracks, bufsize, first_sample, n_samples, f->cur.p};
