@@ -547,9 +547,9 @@ __device__ int g_res_ablate = 0;                    // diagnostic builds: 1 = no
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f4 fnma4(float c, f4 a, f4 b, f4 acc) {      // acc - c * (a - b), one rounding per step
-    return (f4){__builtin_fmaf(-c, __fsub_rn(a.x, b.x), acc.x), __builtin_fmaf(-c, __fsub_rn(a.y, b.y), acc.y),
-                __builtin_fmaf(-c, __fsub_rn(a.z, b.z), acc.z), __builtin_fmaf(-c, __fsub_rn(a.w, b.w), acc.w)};
+__device__ __forceinline__ f4 fnma4(float c, f4 a, f4 b, f4 acc) {      // acc - c * (a - b): a rounded difference, then one fma
+    const f4 d = a - b;                                                  // (vector forms: two floats per v_pk_* instruction)
+    return __builtin_elementwise_fma((f4){-c, -c, -c, -c}, d, acc);
 }
 
 // One exchanged quad = four granules {pressure bits, tag}, each 8 bytes written by one store; the two 16-byte
@@ -663,7 +663,6 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
     unsigned tag = tag_base;
     bool dead = false;                                                  // a neighbour never arrived: stop waiting for good
     const int last = first_sample + n_samples;
-    const unsigned total_steps = (unsigned)n_samples * (unsigned)steps_per_sample;
     unsigned step = 0;
     for (int smp = first_sample; smp < last; ++smp) {
         for (int st = 0; st < steps_per_sample; ++st, ++step) {
@@ -672,7 +671,8 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
             // ---- V: the low faces from the old pressures.  A row with no neighbour in a direction (the room's
             // first row or plane, the row's first cell) reads its OWN pressure there: the difference is +0,
             // -c1 * +0 is -0 for c1 > 0 (checked by the host), and f + -0 = f for every f — the face keeps its
-            // bits without a branch.
+            // bits without a branch.  The rows that wait for a neighbour BLOCK's pressures do the same here and
+            // get their real update below, once those have arrived.
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 unsigned kd = kind[k];
@@ -681,68 +681,24 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 float pl = __shfl_up(pc.w, 1);                          // the cell before the quad: the previous lane's last
                 pl = x0 > 0 ? pl : pc.x;
                 if (!(kd & kOn)) continue;
-                f4 pym = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasYm) ? row_y : 0));
-                f4 pzm = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasZm) ? row_z : 0));
-                if (kd & kFirstY) pym = gpy[k];
-                if (kd & kFirstZ) pzm = gpz[k];
+                const f4 pym = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasYm) ? row_y : 0));
+                const f4 pzm = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasZm) ? row_z : 0));
                 vx4[k] = fnma4(c1, pc, (f4){pl, pc.x, pc.y, pc.z}, vx4[k]);
                 vy4[k] = fnma4(c1, pc, pym, vy4[k]);
                 vz4[k] = fnma4(c1, pc, pzm, vz4[k]);
                 *reinterpret_cast<f4*>(svy + o_own[k]) = vy4[k];
                 *reinterpret_cast<f4*>(svz + o_own[k]) = vz4[k];
-                // the neighbour's low faces above the block's last row / plane: same operation, same operands
-                if (kd & kLastY) gfy[k] = fnma4(c1, gpy[k], pc, gfy[k]);
-                if (kd & kLastZ) gfz[k] = fnma4(c1, gpz[k], pc, gfz[k]);
             }
-            __syncthreads();
-            // ---- P: pressure from the new faces; boundary quads go out write-through as they are made
-            unsigned* const xb = xbuf + (step & 1) * parity_dwords;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                unsigned kd = kind[k];
-                asm volatile("" : "+v"(kd));                        // re-derive the row's predicates here, not in 80 hoisted SGPRs
-                const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
-                if (!(kd & kOn)) continue;
-                f4 hy = *reinterpret_cast<const f4*>(svy + o_own[k] + ((kd & kHasYp) ? row_y : 0));
-                f4 hz = *reinterpret_cast<const f4*>(svz + o_own[k] + ((kd & kHasZp) ? row_z : 0));
-                if (kd & kLastY) hy = gfy[k];
-                if (kd & kLastZ) hz = gfz[k];
-                const f4 pc = p4[k], fx = vx4[k], fy = vy4[k], fz = vz4[k];
-                const float fxh[4] = {fx.y, fx.z, fx.w, fxn};
-                const float fxl[4] = {fx.x, fx.y, fx.z, fx.w};
-                const float hyv[4] = {hy.x, hy.y, hy.z, hy.w}, fyv[4] = {fy.x, fy.y, fy.z, fy.w};
-                const float hzv[4] = {hz.x, hz.y, hz.z, hz.w}, fzv[4] = {fz.x, fz.y, fz.z, fz.w};
-                const float pcv[4] = {pc.x, pc.y, pc.z, pc.w};
-                const bool mj[4] = {(kd & kM0) != 0, (kd & kM12) != 0, (kd & kM12) != 0, (kd & kM3) != 0};
-                float pv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float div = __fadd_rn(__fadd_rn(__fsub_rn(fxh[j], fxl[j]), __fsub_rn(hyv[j], fyv[j])),
-                                                __fsub_rn(hzv[j], fzv[j]));
-                    const float pin = __builtin_fmaf(-c2, div, pcv[j]);
-                    const float pd = __fmul_rn(pcv[j], damp);
-                    pv[j] = mj[j] ? pin : pd;
-                }
-                if (closes && (kd >> kRcvShift) != 0) {                 // the receiver's or the source's quad (two lanes of the room)
-                    const int jr = (int)((kd >> kRcvShift) & 7u) - 1, js = (int)((kd >> kSrcShift) & 7u) - 1;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (j == jr) strip[smp] = __fmul_rn(pv[j], 0.1f);                       // FDTD3D_OUTPUT_SCALE
-                        if (j == js && smp + 1 < last) pv[j] = __fadd_rn(pv[j], inj[smp + 1]);
-                    }
-                }
-                p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
-                *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
-                if (pub_y[k] >= 0) publish_quad(xb + pub_y[k], p4[k], tag);
-                if (pub_z[k] >= 0) publish_quad(xb + pub_z[k], p4[k], tag);
-            }
-            // ---- X: the neighbours' boundary quads, straight into the registers of the thread that uses
-            // them; the granules' tags say when they are this step's (no flag, no fence: guide R2)
-            if (step + 1 < total_steps) {
+            // ---- X: the neighbours' boundary quads of the previous step, straight into the registers of the
+            // thread that uses them; the granules' tags say when they are that step's (no flag, no fence:
+            // guide R2).  They were stored before the interior work above, so the first look usually finds them.
+            if (step > 0) {
+                const unsigned* const xo = xbuf + ((step - 1) & 1) * parity_dwords;
+                const unsigned want = tag - 1;
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
                     unsigned kd = kind[k];
-                asm volatile("" : "+v"(kd));                        // re-derive the row's predicates here, not in 80 hoisted SGPRs
+                    asm volatile("" : "+v"(kd));
                     const bool need_y = pub_y[k] >= 0, need_z = pub_z[k] >= 0;
                     if (!__any(need_y || need_z)) continue;            // the whole wave is interior
 #ifdef GAB_ABLATE
@@ -750,16 +706,16 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
 #endif
                     const int get_y = pub_y[k] + ((kd & kFirstY) ? -up_y : up_y);
                     const int get_z = pub_z[k] + ((kd & kFirstZ) ? -up_z : up_z);
-                    const unsigned* const ry = xb + (need_y ? get_y : need_z ? get_z : 0);
-                    const unsigned* const rz = xb + (need_z ? get_z : need_y ? get_y : 0);
+                    const unsigned* const ry = xo + (need_y ? get_y : need_z ? get_z : 0);
+                    const unsigned* const rz = xo + (need_z ? get_z : need_y ? get_y : 0);
                     bool ok = dead || !(need_y || need_z);
                     unsigned spins = 0;
                     while (!__all(ok)) {
                         u4 a0, a1, b0, b1;
                         fetch_quads(ry, rz, a0, a1, b0, b1);
                         if (!ok) {
-                            const bool oky = a0.y == tag && a0.w == tag && a1.y == tag && a1.w == tag;
-                            const bool okz = b0.y == tag && b0.w == tag && b1.y == tag && b1.w == tag;
+                            const bool oky = a0.y == want && a0.w == want && a1.y == want && a1.w == want;
+                            const bool okz = b0.y == want && b0.w == want && b1.y == want && b1.w == want;
                             if (oky && okz) {
                                 ok = true;
                                 if (need_y) gpy[k] = (f4){__uint_as_float(a0.x), __uint_as_float(a0.z), __uint_as_float(a1.x), __uint_as_float(a1.z)};
@@ -772,6 +728,57 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                         }
                     }
                 }
+            }
+            // ---- V, the rows at the block's faces: the low faces that need the neighbour block's pressures, and
+            // the neighbour's low faces above the block's last row / plane (same operation, same operands as there)
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                unsigned kd = kind[k];
+                asm volatile("" : "+v"(kd));
+                if (!(kd & (kFirstY | kFirstZ | kLastY | kLastZ))) continue;
+                const f4 pc = p4[k];
+                if (kd & kFirstY) {
+                    vy4[k] = fnma4(c1, pc, gpy[k], vy4[k]);
+                    *reinterpret_cast<f4*>(svy + o_own[k]) = vy4[k];
+                }
+                if (kd & kFirstZ) {
+                    vz4[k] = fnma4(c1, pc, gpz[k], vz4[k]);
+                    *reinterpret_cast<f4*>(svz + o_own[k]) = vz4[k];
+                }
+                if (kd & kLastY) gfy[k] = fnma4(c1, gpy[k], pc, gfy[k]);
+                if (kd & kLastZ) gfz[k] = fnma4(c1, gpz[k], pc, gfz[k]);
+            }
+            __syncthreads();
+            // ---- P: pressure from the new faces; boundary quads go out write-through as they are made
+            unsigned* const xb = xbuf + (step & 1) * parity_dwords;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                unsigned kd = kind[k];
+                asm volatile("" : "+v"(kd));
+                const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
+                if (!(kd & kOn)) continue;
+                f4 hy = *reinterpret_cast<const f4*>(svy + o_own[k] + ((kd & kHasYp) ? row_y : 0));
+                f4 hz = *reinterpret_cast<const f4*>(svz + o_own[k] + ((kd & kHasZp) ? row_z : 0));
+                if (kd & kLastY) hy = gfy[k];
+                if (kd & kLastZ) hz = gfz[k];
+                const f4 pc = p4[k], fx = vx4[k];
+                const f4 div = (((f4){fx.y, fx.z, fx.w, fxn} - fx) + (hy - vy4[k])) + (hz - vz4[k]);
+                const f4 pin = __builtin_elementwise_fma((f4){-c2, -c2, -c2, -c2}, div, pc);
+                const f4 pd = pc * damp;
+                float pv[4] = {(kd & kM0) ? pin.x : pd.x, (kd & kM12) ? pin.y : pd.y, (kd & kM12) ? pin.z : pd.z,
+                               (kd & kM3) ? pin.w : pd.w};
+                if (closes && (kd >> kRcvShift) != 0) {                 // the receiver's or the source's quad (two lanes of the room)
+                    const int jr = (int)((kd >> kRcvShift) & 7u) - 1, js = (int)((kd >> kSrcShift) & 7u) - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j == jr) strip[smp] = __fmul_rn(pv[j], 0.1f);                       // FDTD3D_OUTPUT_SCALE
+                        if (j == js && smp + 1 < last) pv[j] = __fadd_rn(pv[j], inj[smp + 1]);
+                    }
+                }
+                p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
+                *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
+                if (pub_y[k] >= 0) publish_quad(xb + pub_y[k], p4[k], tag);
+                if (pub_z[k] >= 0) publish_quad(xb + pub_z[k], p4[k], tag);
             }
             __syncthreads();
         }
