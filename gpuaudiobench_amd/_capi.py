@@ -104,6 +104,7 @@ PROTOTYPES = {
     "gab_fdtd_reset": (_I, [_P, _P]),
     "gab_fdtd_process": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "gab_fdtd_copy_pressure": (_I, [_P, _P, _P]),
+    "gab_fdtd_resident": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "gab_fdtd_set_track_positions": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I]),
     "gab_fdtd_create_slab": (_I, [C.POINTER(_P), C.POINTER(FdtdParams), _I, _I]),
     "gab_fdtd_owns": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),

@@ -980,6 +980,11 @@ size_t FDTD3DBenchmark::algorithmicBytes() const {
     return per_step * kFDTD3D_StepsPerSample * getBufferSize();
 }
 
+bool FDTD3DBenchmark::workingSetOnChip() const {
+    int resident = 0;
+    return plan_ && gab_fdtd_resident(plan_, &resident, nullptr) == GAB_OK && resident != 0;
+}
+
 // ===========================================================================
 // RndMemRead
 // ===========================================================================

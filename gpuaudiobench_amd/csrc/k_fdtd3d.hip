@@ -539,9 +539,11 @@ struct ResidentGeom {
 constexpr int kResThreads = 1024;
 constexpr int kResRowSlots = kResThreads / 32;      // a row of up to 128 cells = 32 lanes x float4
 constexpr int kResRowDwords = 256;                  // one exchanged row: 128 granules {pressure, tag}
-constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling before giving up
 #ifdef GAB_ABLATE
-__device__ int g_res_ablate = 0;                    // diagnostic builds: 1 = no exchange between workgroups (wrong results)
+constexpr unsigned kResSpinLimit = 1u << 13;        // diagnostic builds: give up after milliseconds (tools/fdtd_timeout_check.py)
+__device__ int g_res_ablate = 0;                    // 1 = no exchange between workgroups (wrong results); 2 = workgroup 0 never publishes
+#else
+constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling before giving up
 #endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -777,6 +779,9 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 }
                 p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
                 *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
+#ifdef GAB_ABLATE
+                if ((g_res_ablate & 2) && wg == 0) continue;
+#endif
                 if (pub_y[k] >= 0) publish_quad(xb + pub_y[k], p4[k], tag);
                 if (pub_z[k] >= 0) publish_quad(xb + pub_z[k], p4[k], tag);
             }
@@ -1102,6 +1107,14 @@ int gab_fdtd_reset(gab_fdtd_plan* f, gab_stream_t stream) {
         zero_fields(f->nxt_real, *f, s);
         return GAB_OK;
     });
+}
+
+int gab_fdtd_resident(const gab_fdtd_plan* f, int* resident, int* workgroups) {
+    if (!f) return gab::bad_arg("gab_fdtd_resident: null plan");
+    const bool r = f->resident && f->res_rpt > 0 && !f->pos_tracks;
+    if (resident) *resident = r ? 1 : 0;
+    if (workgroups) *workgroups = r ? f->rgeom.gy * f->rgeom.gz : 0;
+    return GAB_OK;
 }
 
 int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int tracks, int bufsize,

@@ -239,6 +239,12 @@ class FdtdPlan:
                                    n_samples, _stream()))
         return out
 
+    def resident(self):
+        """(takes the LDS-resident whole-buffer kernel, its workgroups): gab_fdtd_resident."""
+        r, w = C.c_int(0), C.c_int(0)
+        check(lib.gab_fdtd_resident(self._h, C.byref(r), C.byref(w)))
+        return bool(r.value), w.value
+
     def set_track_positions(self, src_xyz, rcv_xyz):
         """Per-track source and receiver cells: two (tracks, 3) integer arrays of (x, y, z);
         pass None, None to return to the shared cells of the params."""

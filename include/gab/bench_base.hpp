@@ -109,6 +109,9 @@ public:
     virtual void resetState() {}
     virtual void runValidationIteration() { resetState(); performBenchmarkIteration(); }
     virtual size_t algorithmicBytes() const { return 2 * getTotalElements() * sizeof(float); }
+    // true when the kernel keeps its working set on chip for the whole iteration, so that the HBM roofline
+    // the algorithmic bytes are priced against does not bound it (FDTD3D rooms that fit the LDS)
+    virtual bool workingSetOnChip() const { return false; }
     // The CPU golden of tracks [first, first + count) recomputed into the benchmark's own reference
     // buffer (what setupBenchmark already did once); false when the golden cannot be cut by track.
     // timeCpuGolden() runs it over `threads` host threads (1 when it cannot be cut) and returns the

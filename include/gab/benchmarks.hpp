@@ -435,6 +435,7 @@ public:
     void validate(ValidationData& validation_data) override;
     void resetState() override;
     size_t algorithmicBytes() const override;     // per buffer = per-step bytes * 3 * B
+    bool workingSetOnChip() const override;
     const FDTD3DParams& params() const { return *h_fdtd3d_params; }
     // error against the real field evolution (gab::golden::fdtd3d), not the placeholder
     float fieldMaxError() const { return field_max_error_; }

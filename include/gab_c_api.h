@@ -211,6 +211,15 @@ int gab_fdtd_reset(gab_fdtd_plan* plan, gab_stream_t stream);     /* zero grids 
 int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
                      int tracks, int bufsize, int first_sample, int n_samples,
                      gab_stream_t stream);
+/* Which form gab_fdtd_process takes.  A room whose four fields fit the chip's LDS (nx a multiple of 4, 8..128;
+ * up to 8192 cells per compute unit: 128^3 on 256 CUs) runs a whole buffer in ONE launch with the fields
+ * resident in LDS and registers, one block of rows per workgroup, the blocks' boundary pressures handed to the
+ * neighbours through memory every step (same bits as the step kernels, 3x their speed at 128^3).  It needs
+ * every workgroup on the device at once: a workgroup that waits about a second for a neighbour gives up, the
+ * NEXT call returns GAB_ERR_RUNTIME and the plan uses the step kernels from then on.  Larger rooms, z-slabs,
+ * per-track positions and calls inside a stream capture use the step kernels.
+ * *resident = 1 when the next call (outside a capture) takes the resident form, *workgroups = its grid. */
+int gab_fdtd_resident(const gab_fdtd_plan* plan, int* resident, int* workgroups);
 /* Track-dependent source and receiver cells — announced and never done by the Metal port
  * ("can be made track-dependent later", kernels_fdtd3d.metal:184,217).  src_xyz / rcv_xyz: HOST
  * arrays, tracks x (x, y, z).  From then on gab_fdtd_process (with that many tracks) adds

@@ -618,6 +618,8 @@ def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     grids = orc.fdtd_grids(P)
     ref = np.zeros(T * B, np.float32)
     plan = gab.FdtdPlan(G)
+    # rows of 4..128 cells in multiples of four whose fields fit the LDS take the resident whole-buffer kernel
+    assert plan.resident()[0] == (n in (20, 52, 128, 100))
     out = torch.zeros(T * B, device="cuda")
     half = samples // 2
     for first, cnt in ((0, half), (half, samples - half)):       # state carries across calls
@@ -628,6 +630,35 @@ def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     assert np.abs(grids[0]).max() > 0
     plan.reset()
     assert not host(plan.pressure()).any()
+    plan.close()
+
+
+@pytest.mark.parametrize("dims", [(8, 6, 5), (24, 21, 19), (64, 30, 9), (128, 5, 7), (12, 64, 64), (128, 40, 50)])
+def test_fdtd_resident_rooms(gab, orc, dims):
+    """The LDS-resident kernel on rooms that are not cubes: blocks that do not divide the room (a clipped last
+    block in y and in z), one-quad and full-width rows, more workgroups along one axis than the other; several
+    calls in a row (the exchange tags go on across launches), a reset in between, source and receiver placed by
+    the reference's proportions.  Bit for bit the oracle's fields and outputs."""
+    import torch
+    nx, ny, nz = dims
+    P = orc.fdtd_params(nx, ny, nz)
+    G = gab.fdtd_default_params(nx, ny, nz)
+    T, B = 3, 10
+    plan = gab.FdtdPlan(G)
+    is_resident, workgroups = plan.resident()
+    assert is_resident and 2 <= workgroups <= torch.cuda.get_device_properties(0).multi_processor_count
+    for rnd in range(2):
+        x = orc.Rand(7 + rnd).bipolar(T * B)
+        grids = orc.fdtd_grids(P)
+        ref = np.zeros(T * B, np.float32)
+        out = torch.zeros(T * B, device="cuda")
+        for first, cnt in ((0, 1), (1, 6), (7, 3)):
+            orc.fdtd(P, grids, x, ref, T, B, first, cnt, fused=True)
+            plan.process(dev(x), out, T, B, first, cnt)
+        assert np.array_equal(bits(host(out)), bits(ref))
+        assert np.array_equal(bits(host(plan.pressure()).ravel()), bits(grids[0]))
+        assert np.abs(grids[0]).max() > 0
+        plan.reset()
     plan.close()
 
 
