@@ -620,12 +620,25 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
     unsigned kind[RPT];
     const int up_y = 3 * rg.fr * kResRowDwords;                        // from my y+ row to the next block's y- row (and back: minus)
     const int up_z = (4 * rg.gy - 1) * rg.fr * kResRowDwords;          // from my z+ row to the next plane of blocks' z- row
+    // Rows are dealt to the slots FACE ROWS FIRST (the block's two z faces, then its two y faces, then the
+    // interior): the rows whose pressures the neighbours wait for are every thread's first row, made and stored
+    // at the head of the pressure phase, so that their way through memory overlaps the interior rows' work.
+    const int n_face = rg.rows - (by - 2) * (bz - 2);
+    auto row_of = [&](int q, int& ly, int& lz) {
+        if (q < by) { ly = q; lz = 0; }
+        else if (q < 2 * by) { ly = q - by; lz = bz - 1; }
+        else if (q < 2 * by + (bz - 2)) { ly = 0; lz = 1 + q - 2 * by; }
+        else if (q < n_face) { ly = by - 1; lz = 1 + q - 2 * by - (bz - 2); }
+        else { const int i = q - n_face; ly = 1 + i % (by - 2); lz = 1 + i / (by - 2); }
+    };
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int r = slot + kResRowSlots * k;
-        const int ly = r % by, lz = r / by;
+        const int q = slot + kResRowSlots * k;
+        int ly = 0, lz = 0;
+        row_of(q < rg.rows ? q : 0, ly, lz);
+        const int r = lz * by + ly;
         const int y = y0 + ly, z = z0 + lz;
-        const bool on = xq < rg.nq && r < rg.rows && y < ny && z < nz;
+        const bool on = xq < rg.nq && q < rg.rows && y < ny && z < nz;
         const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
         o_own[k] = r * nx + x0;
         const bool first_y = on && ly == 0 && has_ym, last_y = on && ly == by - 1 && has_yp;
@@ -792,8 +805,9 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         if (!(kind[k] & kOn)) continue;
-        const int r = slot + kResRowSlots * k;
-        const int y = y0 + r % by, z = z0 + r / by;
+        int ly = 0, lz = 0;
+        row_of(slot + kResRowSlots * k, ly, lz);
+        const int y = y0 + ly, z = z0 + lz;
         const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
         *reinterpret_cast<f4*>(f.p + pi) = p4[k];
         *reinterpret_cast<f4*>(f.vx + ((size_t)z * ny + y) * px + x0) = vx4[k];
