@@ -541,6 +541,7 @@ constexpr int kResRowSlots = kResThreads / 32;      // a row of up to 128 cells 
 constexpr int kResRowDwords = 256;                  // one exchanged row: 128 granules {pressure, tag}
 #ifdef GAB_ABLATE
 constexpr unsigned kResSpinLimit = 1u << 13;        // diagnostic builds: give up after milliseconds (tools/fdtd_timeout_check.py)
+__device__ unsigned long long g_res_rounds[4];      // poll rounds, poll loops, clocks spent in the loops (one lane per wave counts)
 __device__ int g_res_ablate = 0;                    // 1 = no exchange between workgroups (wrong results); 2 = workgroup 0 never publishes
 #else
 constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling before giving up
@@ -571,6 +572,12 @@ __device__ __forceinline__ void fetch_quads(const unsigned* ry, const unsigned* 
                  "global_load_dwordx4 %3, %5, off offset:512 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(y0), "=&v"(y1), "=&v"(z0), "=&v"(z1) : "v"(ry), "v"(rz) : "memory");
+}
+__device__ __forceinline__ void fetch_quad(const unsigned* r, u4& q0, u4& q1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:512 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1) : "v"(r) : "memory");
 }
 __device__ __forceinline__ unsigned peek_sc1(const unsigned* p) {
     unsigned v;
@@ -724,10 +731,26 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                     const unsigned* const ry = xo + (need_y ? get_y : need_z ? get_z : 0);
                     const unsigned* const rz = xo + (need_z ? get_z : need_y ? get_y : 0);
                     bool ok = dead || !(need_y || need_z);
+                    const bool both = __any(need_y && need_z);          // (uniform) an edge row of the block in this wave
                     unsigned spins = 0;
+#ifdef GAB_ABLATE
+                    unsigned rounds = 0;
+                    const unsigned long long t_drain = __builtin_amdgcn_s_memtime();
+                    if (g_res_ablate & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+#endif
                     while (!__all(ok)) {
                         u4 a0, a1, b0, b1;
-                        fetch_quads(ry, rz, a0, a1, b0, b1);
+                        if (both) {
+                            fetch_quads(ry, rz, a0, a1, b0, b1);
+                        } else {                                        // ry == rz wherever one is needed
+                            if (need_y || need_z) fetch_quad(ry, a0, a1);
+                            b0 = a0;
+                            b1 = a1;
+                        }
+#ifdef GAB_ABLATE
+                        ++rounds;
+#endif
                         if (!ok) {
                             const bool oky = a0.y == want && a0.w == want && a1.y == want && a1.w == want;
                             const bool okz = b0.y == want && b0.w == want && b1.y == want && b1.w == want;
@@ -742,6 +765,14 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                             }
                         }
                     }
+#ifdef GAB_ABLATE
+                    if ((g_res_ablate & 4) && (tid & 63) == 0 && wg == (int)gridDim.x / 2 + 1) {
+                        atomicAdd(&g_res_rounds[0], (unsigned long long)rounds);
+                        atomicAdd(&g_res_rounds[1], 1ull);
+                        atomicAdd(&g_res_rounds[2], __builtin_amdgcn_s_memtime() - t_in);
+                        atomicAdd(&g_res_rounds[3], t_in - t_drain);
+                    }
+#endif
                 }
             }
             // ---- V, the rows at the block's faces: the low faces that need the neighbour block's pressures, and
@@ -1122,6 +1153,12 @@ int gab_fdtd_reset(gab_fdtd_plan* f, gab_stream_t stream) {
         return GAB_OK;
     });
 }
+
+#ifdef GAB_ABLATE
+extern "C" int gab_debug_fdtd_rounds(unsigned long long* h_out) {
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_res_rounds), sizeof(unsigned long long) * 4);
+}
+#endif
 
 int gab_fdtd_resident(const gab_fdtd_plan* f, int* resident, int* workgroups) {
     if (!f) return gab::bad_arg("gab_fdtd_resident: null plan");

@@ -1,4 +1,5 @@
 """Times the FDTD3D plan: grid n^3, `samples` audio samples (3 leapfrog steps each)."""
+import os
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -31,3 +32,10 @@ for rep in range(4):          # rep 0 pays the hipGraph capture for this signatu
     print("rep %d grid %d^3 T=%d: %d steps in %.3f ms device (%.3f ms wall) -> %.2f us/step, %.0f GB/s algorithmic (%.1f%% of 8 TB/s)"
           % (rep, n, T, steps, ms, wall, ms * 1e3 / steps, alg / (ms * 1e-3 / steps) / 1e9,
              alg / (ms * 1e-3 / steps) / 8e12 * 100))
+if os.environ.get("GAB_FDTD_RES_ABLATE", "0") != "0" and hasattr(gab.lib, "gab_debug_fdtd_rounds"):
+    import ctypes
+    r = (ctypes.c_ulonglong * 4)()
+    gab.lib.gab_debug_fdtd_rounds(r)
+    if r[1]:
+        print("resident kernel polls (one lane per wave): %.2f rounds per poll loop, %.0f clocks per loop, %.0f clocks draining the stores before it, %d loops"
+              % (r[0] / r[1], r[2] / r[1], r[3] / r[1], r[1]))
