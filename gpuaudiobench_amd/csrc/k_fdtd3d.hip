@@ -622,14 +622,18 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         kM0 = 512u, kM12 = 1024u, kM3 = 2048u,                                // which cells of the quad are interior cells of the room
         kRcvShift = 12, kSrcShift = 15                                        // 1 + j of the receiver / source cell (0: not here)
     };
-    f4 p4[RPT], vx4[RPT], vy4[RPT], vz4[RPT], gpy[RPT], gpz[RPT], gfy[RPT], gfz[RPT];
-    int o_own[RPT], pub_y[RPT], pub_z[RPT];
+    // Face rows are every thread's FIRST row (the host only takes geometries whose face rows fit the row slots):
+    // the ghost state exists once per thread, not once per row.
+    f4 p4[RPT], vx4[RPT], vy4[RPT], vz4[RPT];
+    f4 gpy, gpz, gfy, gfz;
+    gpy = gpz = gfy = gfz = (f4){0.f, 0.f, 0.f, 0.f};
+    int o_own[RPT], pub_y = -1, pub_z = -1;
     unsigned kind[RPT];
     const int up_y = 3 * rg.fr * kResRowDwords;                        // from my y+ row to the next block's y- row (and back: minus)
     const int up_z = (4 * rg.gy - 1) * rg.fr * kResRowDwords;          // from my z+ row to the next plane of blocks' z- row
     // Rows are dealt to the slots FACE ROWS FIRST (the block's two z faces, then its two y faces, then the
-    // interior): the rows whose pressures the neighbours wait for are every thread's first row, made and stored
-    // at the head of the pressure phase, so that their way through memory overlaps the interior rows' work.
+    // interior): the rows whose pressures the neighbours wait for are made and stored at the head of the
+    // pressure phase, so that their way through memory overlaps the interior rows' work.
     const int n_face = rg.rows - (by - 2) * (bz - 2);
     auto row_of = [&](int q, int& ly, int& lz) {
         if (q < by) { ly = q; lz = 0; }
@@ -648,16 +652,19 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         const bool on = xq < rg.nq && q < rg.rows && y < ny && z < nz;
         const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
         o_own[k] = r * nx + x0;
-        const bool first_y = on && ly == 0 && has_ym, last_y = on && ly == by - 1 && has_yp;
-        const bool first_z = on && lz == 0 && has_zm, last_z = on && lz == bz - 1 && has_zp;
-        pub_y[k] = first_y ? xrow(wg, 0, lz) : last_y ? xrow(wg, 1, lz) : -1;
-        pub_z[k] = first_z ? xrow(wg, 2, ly) : last_z ? xrow(wg, 3, ly) : -1;
+        const bool face = k == 0;                                      // (rows of the later slots are interior rows)
+        const bool first_y = face && on && ly == 0 && has_ym, last_y = face && on && ly == by - 1 && has_yp;
+        const bool first_z = face && on && lz == 0 && has_zm, last_z = face && on && lz == bz - 1 && has_zp;
+        if (face) {
+            pub_y = first_y ? xrow(wg, 0, lz) : last_y ? xrow(wg, 1, lz) : -1;
+            pub_z = first_z ? xrow(wg, 2, ly) : last_z ? xrow(wg, 3, ly) : -1;
+        }
         const bool row_interior = y > 0 && y < ny - 1 && z > 0 && z < nz - 1;
         unsigned kd = (on ? kOn : 0u) | (ly > 0 ? kHasYm : 0u) | (lz > 0 ? kHasZm : 0u) | (ly + 1 < by ? kHasYp : 0u) |
                       (lz + 1 < bz ? kHasZp : 0u) | (first_y ? kFirstY : 0u) | (first_z ? kFirstZ : 0u) |
                       (last_y ? kLastY : 0u) | (last_z ? kLastZ : 0u) | (row_interior && x0 > 0 ? kM0 : 0u) |
                       (row_interior ? kM12 : 0u) | (row_interior && x0 + 4 < nx ? kM3 : 0u);
-        p4[k] = vx4[k] = vy4[k] = vz4[k] = gpy[k] = gpz[k] = gfy[k] = gfz[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        p4[k] = vx4[k] = vy4[k] = vz4[k] = (f4){0.f, 0.f, 0.f, 0.f};
         if (on) {
             if (rcv >= pi && rcv < pi + 4) kd |= (unsigned)(rcv - pi + 1) << kRcvShift;
             if (src >= pi && src < pi + 4) kd |= (unsigned)(src - pi + 1) << kSrcShift;
@@ -665,21 +672,33 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
             vx4[k] = *reinterpret_cast<const f4*>(f.vx + ((size_t)z * ny + y) * px + x0);
             vy4[k] = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0);
             vz4[k] = *reinterpret_cast<const f4*>(f.vz + pi);
-            if (first_y) gpy[k] = *reinterpret_cast<const f4*>(f.p + pi - nx);
+            if (first_y) gpy = *reinterpret_cast<const f4*>(f.p + pi - nx);
             if (last_y) {
-                gpy[k] = *reinterpret_cast<const f4*>(f.p + pi + nx);
-                gfy[k] = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y + 1) * nx + x0);
+                gpy = *reinterpret_cast<const f4*>(f.p + pi + nx);
+                gfy = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y + 1) * nx + x0);
             }
-            if (first_z) gpz[k] = *reinterpret_cast<const f4*>(f.p + pi - sxy);
+            if (first_z) gpz = *reinterpret_cast<const f4*>(f.p + pi - sxy);
             if (last_z) {
-                gpz[k] = *reinterpret_cast<const f4*>(f.p + pi + sxy);
-                gfz[k] = *reinterpret_cast<const f4*>(f.vz + pi + sxy);
+                gpz = *reinterpret_cast<const f4*>(f.p + pi + sxy);
+                gfz = *reinterpret_cast<const f4*>(f.vz + pi + sxy);
             }
             *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
         }
         kind[k] = kd;
     }
     __syncthreads();
+
+    // where this thread's ghost quads come from (byte offsets into one parity of xbuf); a thread that needs none
+    // asks beyond the descriptor's range: the hardware drops that load and returns zeros
+    const bool need_y = pub_y >= 0, need_z = pub_z >= 0;
+    const unsigned kNowhere = 0xfffff000u;
+    const unsigned get_y = need_y ? 4u * (unsigned)(pub_y + ((kind[0] & kFirstY) ? -up_y : up_y)) : kNowhere;
+    const unsigned get_z = need_z ? 4u * (unsigned)(pub_z + ((kind[0] & kFirstZ) ? -up_z : up_z)) : kNowhere;
+    const auto xsrd0 = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, 4 * parity_dwords, 0x00020000);
+    const auto xsrd1 = __builtin_amdgcn_make_buffer_rsrc(xbuf + parity_dwords, 0, 4 * parity_dwords, 0x00020000);
+    auto ask = [&](bool odd, unsigned off) -> u4 {                     // one 16-byte sc1 load the compiler keeps track of
+        return odd ? __builtin_amdgcn_raw_buffer_load_b128(xsrd1, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(xsrd0, off, 0, 16);
+    };
 
     const int row_y = nx, row_z = by * nx;                              // LDS strides
     unsigned tag = tag_base;
@@ -690,6 +709,13 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         for (int st = 0; st < steps_per_sample; ++st, ++step) {
             const bool closes = st == steps_per_sample - 1;
             ++tag;
+            // ---- X, first half: ask for the neighbours' boundary quads of the previous step (stored at the head
+            // of its pressure phase, an interior row's worth of work ago); they are looked at after the faces below
+            const bool odd = ((step - 1) & 1) != 0;
+            const bool polls = step > 0 && !dead;
+            const unsigned ay = polls ? get_y : kNowhere, az = polls ? get_z : kNowhere;
+            u4 a0 = ask(odd, ay), a1 = ask(odd, ay + 512), b0 = ask(odd, az), b1 = ask(odd, az + 512);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- V: the low faces from the old pressures.  A row with no neighbour in a direction (the room's
             // first row or plane, the row's first cell) reads its OWN pressure there: the difference is +0,
             // -c1 * +0 is -0 for c1 > 0 (checked by the host), and f + -0 = f for every f — the face keeps its
@@ -711,91 +737,69 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 *reinterpret_cast<f4*>(svy + o_own[k]) = vy4[k];
                 *reinterpret_cast<f4*>(svz + o_own[k]) = vz4[k];
             }
-            // ---- X: the neighbours' boundary quads of the previous step, straight into the registers of the
-            // thread that uses them; the granules' tags say when they are that step's (no flag, no fence:
-            // guide R2).  They were stored before the interior work above, so the first look usually finds them.
-            if (step > 0) {
-                const unsigned* const xo = xbuf + ((step - 1) & 1) * parity_dwords;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- X, second half: the granules' tags say whether they are that step's (no flag, no fence: guide
+            // R2); a thread whose quads were not there yet asks again until they are
+            if (polls) {
                 const unsigned want = tag - 1;
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    unsigned kd = kind[k];
-                    asm volatile("" : "+v"(kd));
-                    const bool need_y = pub_y[k] >= 0, need_z = pub_z[k] >= 0;
-                    if (!__any(need_y || need_z)) continue;            // the whole wave is interior
 #ifdef GAB_ABLATE
-                    if (g_res_ablate & 1) continue;
+                unsigned rounds = 0;
 #endif
-                    const int get_y = pub_y[k] + ((kd & kFirstY) ? -up_y : up_y);
-                    const int get_z = pub_z[k] + ((kd & kFirstZ) ? -up_z : up_z);
-                    const unsigned* const ry = xo + (need_y ? get_y : need_z ? get_z : 0);
-                    const unsigned* const rz = xo + (need_z ? get_z : need_y ? get_y : 0);
-                    bool ok = dead || !(need_y || need_z);
-                    const bool both = __any(need_y && need_z);          // (uniform) an edge row of the block in this wave
-                    unsigned spins = 0;
+                bool ok = !(need_y || need_z);
 #ifdef GAB_ABLATE
-                    unsigned rounds = 0;
-                    const unsigned long long t_drain = __builtin_amdgcn_s_memtime();
-                    if (g_res_ablate & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+                if (g_res_ablate & 1) ok = true;
 #endif
-                    while (!__all(ok)) {
-                        u4 a0, a1, b0, b1;
-                        if (both) {
-                            fetch_quads(ry, rz, a0, a1, b0, b1);
-                        } else {                                        // ry == rz wherever one is needed
-                            if (need_y || need_z) fetch_quad(ry, a0, a1);
-                            b0 = a0;
-                            b1 = a1;
-                        }
-#ifdef GAB_ABLATE
-                        ++rounds;
-#endif
-                        if (!ok) {
-                            const bool oky = a0.y == want && a0.w == want && a1.y == want && a1.w == want;
-                            const bool okz = b0.y == want && b0.w == want && b1.y == want && b1.w == want;
-                            if (oky && okz) {
-                                ok = true;
-                                if (need_y) gpy[k] = (f4){__uint_as_float(a0.x), __uint_as_float(a0.z), __uint_as_float(a1.x), __uint_as_float(a1.z)};
-                                if (need_z) gpz[k] = (f4){__uint_as_float(b0.x), __uint_as_float(b0.z), __uint_as_float(b1.x), __uint_as_float(b1.z)};
-                            } else if ((++spins & 1023u) == 0) {       // a long wait: has anyone given up? is it time to?
-                                if (spins > kResSpinLimit)
-                                    __hip_atomic_store(timeout_word, 1u + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (spins > kResSpinLimit || peek_sc1(timeout_word) != 0) ok = dead = true;
-                            }
+                unsigned spins = 0;
+                for (;;) {
+                    if (!ok) {
+                        const bool oky = !need_y || (a0.y == want && a0.w == want && a1.y == want && a1.w == want);
+                        const bool okz = !need_z || (b0.y == want && b0.w == want && b1.y == want && b1.w == want);
+                        if (oky && okz) {
+                            ok = true;
+                            if (need_y) gpy = (f4){__uint_as_float(a0.x), __uint_as_float(a0.z), __uint_as_float(a1.x), __uint_as_float(a1.z)};
+                            if (need_z) gpz = (f4){__uint_as_float(b0.x), __uint_as_float(b0.z), __uint_as_float(b1.x), __uint_as_float(b1.z)};
+                        } else if ((++spins & 1023u) == 0) {           // a long wait: has anyone given up? is it time to?
+                            if (spins > kResSpinLimit)
+                                __hip_atomic_store(timeout_word, 1u + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (spins > kResSpinLimit || peek_sc1(timeout_word) != 0) ok = dead = true;
                         }
                     }
+                    if (__all(ok)) break;
+                    const unsigned ry = ok ? kNowhere : get_y, rz = ok ? kNowhere : get_z;
+                    a0 = ask(odd, ry), a1 = ask(odd, ry + 512), b0 = ask(odd, rz), b1 = ask(odd, rz + 512);
 #ifdef GAB_ABLATE
-                    if ((g_res_ablate & 4) && (tid & 63) == 0 && wg == (int)gridDim.x / 2 + 1) {
-                        atomicAdd(&g_res_rounds[0], (unsigned long long)rounds);
-                        atomicAdd(&g_res_rounds[1], 1ull);
-                        atomicAdd(&g_res_rounds[2], __builtin_amdgcn_s_memtime() - t_in);
-                        atomicAdd(&g_res_rounds[3], t_in - t_drain);
-                    }
+                    ++rounds;
 #endif
                 }
+#ifdef GAB_ABLATE
+                if ((g_res_ablate & 4) && (tid & 63) == 0 && wg == (int)gridDim.x / 2 + 1) {
+                    atomicAdd(&g_res_rounds[0], (unsigned long long)rounds);
+                    atomicAdd(&g_res_rounds[1], 1ull);
+                }
+#endif
             }
             // ---- V, the rows at the block's faces: the low faces that need the neighbour block's pressures, and
             // the neighbour's low faces above the block's last row / plane (same operation, same operands as there)
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                unsigned kd = kind[k];
+            {
+                unsigned kd = kind[0];
                 asm volatile("" : "+v"(kd));
-                if (!(kd & (kFirstY | kFirstZ | kLastY | kLastZ))) continue;
-                const f4 pc = p4[k];
-                if (kd & kFirstY) {
-                    vy4[k] = fnma4(c1, pc, gpy[k], vy4[k]);
-                    *reinterpret_cast<f4*>(svy + o_own[k]) = vy4[k];
+                if (kd & (kFirstY | kFirstZ | kLastY | kLastZ)) {
+                    const f4 pc = p4[0];
+                    if (kd & kFirstY) {
+                        vy4[0] = fnma4(c1, pc, gpy, vy4[0]);
+                        *reinterpret_cast<f4*>(svy + o_own[0]) = vy4[0];
+                    }
+                    if (kd & kFirstZ) {
+                        vz4[0] = fnma4(c1, pc, gpz, vz4[0]);
+                        *reinterpret_cast<f4*>(svz + o_own[0]) = vz4[0];
+                    }
+                    if (kd & kLastY) gfy = fnma4(c1, gpy, pc, gfy);
+                    if (kd & kLastZ) gfz = fnma4(c1, gpz, pc, gfz);
                 }
-                if (kd & kFirstZ) {
-                    vz4[k] = fnma4(c1, pc, gpz[k], vz4[k]);
-                    *reinterpret_cast<f4*>(svz + o_own[k]) = vz4[k];
-                }
-                if (kd & kLastY) gfy[k] = fnma4(c1, gpy[k], pc, gfy[k]);
-                if (kd & kLastZ) gfz[k] = fnma4(c1, gpz[k], pc, gfz[k]);
             }
             __syncthreads();
-            // ---- P: pressure from the new faces; boundary quads go out write-through as they are made
+            // ---- P: pressure from the new faces; the face rows first, their quads stored write-through as they
+            // are made
             unsigned* const xb = xbuf + (step & 1) * parity_dwords;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
@@ -805,8 +809,10 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 if (!(kd & kOn)) continue;
                 f4 hy = *reinterpret_cast<const f4*>(svy + o_own[k] + ((kd & kHasYp) ? row_y : 0));
                 f4 hz = *reinterpret_cast<const f4*>(svz + o_own[k] + ((kd & kHasZp) ? row_z : 0));
-                if (kd & kLastY) hy = gfy[k];
-                if (kd & kLastZ) hz = gfz[k];
+                if (k == 0) {
+                    if (kd & kLastY) hy = gfy;
+                    if (kd & kLastZ) hz = gfz;
+                }
                 const f4 pc = p4[k], fx = vx4[k];
                 const f4 div = (((f4){fx.y, fx.z, fx.w, fxn} - fx) + (hy - vy4[k])) + (hz - vz4[k]);
                 const f4 pin = __builtin_elementwise_fma((f4){-c2, -c2, -c2, -c2}, div, pc);
@@ -823,11 +829,13 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 }
                 p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
                 *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
+                if (k == 0) {
 #ifdef GAB_ABLATE
-                if ((g_res_ablate & 2) && wg == 0) continue;
+                    if ((g_res_ablate & 2) && wg == 0) continue;
 #endif
-                if (pub_y[k] >= 0) publish_quad(xb + pub_y[k], p4[k], tag);
-                if (pub_z[k] >= 0) publish_quad(xb + pub_z[k], p4[k], tag);
+                    if (pub_y >= 0) publish_quad(xb + pub_y, p4[0], tag);
+                    if (pub_z >= 0) publish_quad(xb + pub_z, p4[0], tag);
+                }
             }
             __syncthreads();
         }
@@ -960,6 +968,7 @@ void choose_resident_geometry(gab_fdtd_plan* f) {
         for (int by = 2; by <= 32; ++by) {
             const int rows = by * bz;
             if (rows > 2 * gab::kResRowSlots) continue;
+            if (rows > gab::kResRowSlots && 2 * (by + bz) - 4 > gab::kResRowSlots) continue;   // face rows: every thread's first row
             const long gy = (P.ny + by - 1) / by, gz = (P.nz + bz - 1) / bz, w = gy * gz;
             if (w > cus || w < 2) continue;
             const size_t floats = (size_t)3 * rows * P.nx;                  // p, vy, vz images
