@@ -627,7 +627,7 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
     f4 p4[RPT], vx4[RPT], vy4[RPT], vz4[RPT];
     f4 gpy, gpz, gfy, gfz;
     gpy = gpz = gfy = gfz = (f4){0.f, 0.f, 0.f, 0.f};
-    int o_own[RPT], pub_y = -1, pub_z = -1;
+    int o_own[RPT], o_ym[RPT], o_zm[RPT], o_yp[RPT], o_zp[RPT], pub_y = -1, pub_z = -1;     // LDS float offsets (own row where there is no neighbour row)
     unsigned kind[RPT];
     const int up_y = 3 * rg.fr * kResRowDwords;                        // from my y+ row to the next block's y- row (and back: minus)
     const int up_z = (4 * rg.gy - 1) * rg.fr * kResRowDwords;          // from my z+ row to the next plane of blocks' z- row
@@ -652,6 +652,10 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         const bool on = xq < rg.nq && q < rg.rows && y < ny && z < nz;
         const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
         o_own[k] = r * nx + x0;
+        o_ym[k] = o_own[k] - (ly > 0 ? nx : 0);
+        o_zm[k] = o_own[k] - (lz > 0 ? by * nx : 0);
+        o_yp[k] = o_own[k] + (ly + 1 < by ? nx : 0);
+        o_zp[k] = o_own[k] + (lz + 1 < bz ? by * nx : 0);
         const bool face = k == 0;                                      // (rows of the later slots are interior rows)
         const bool first_y = face && on && ly == 0 && has_ym, last_y = face && on && ly == by - 1 && has_yp;
         const bool first_z = face && on && lz == 0 && has_zm, last_z = face && on && lz == bz - 1 && has_zp;
@@ -700,7 +704,6 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         return odd ? __builtin_amdgcn_raw_buffer_load_b128(xsrd1, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(xsrd0, off, 0, 16);
     };
 
-    const int row_y = nx, row_z = by * nx;                              // LDS strides
     unsigned tag = tag_base;
     bool dead = false;                                                  // a neighbour never arrived: stop waiting for good
     const int last = first_sample + n_samples;
@@ -729,8 +732,8 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 float pl = __shfl_up(pc.w, 1);                          // the cell before the quad: the previous lane's last
                 pl = x0 > 0 ? pl : pc.x;
                 if (!(kd & kOn)) continue;
-                const f4 pym = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasYm) ? row_y : 0));
-                const f4 pzm = *reinterpret_cast<const f4*>(sp + o_own[k] - ((kd & kHasZm) ? row_z : 0));
+                const f4 pym = *reinterpret_cast<const f4*>(sp + o_ym[k]);
+                const f4 pzm = *reinterpret_cast<const f4*>(sp + o_zm[k]);
                 vx4[k] = fnma4(c1, pc, (f4){pl, pc.x, pc.y, pc.z}, vx4[k]);
                 vy4[k] = fnma4(c1, pc, pym, vy4[k]);
                 vz4[k] = fnma4(c1, pc, pzm, vz4[k]);
@@ -807,8 +810,8 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 asm volatile("" : "+v"(kd));
                 const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
                 if (!(kd & kOn)) continue;
-                f4 hy = *reinterpret_cast<const f4*>(svy + o_own[k] + ((kd & kHasYp) ? row_y : 0));
-                f4 hz = *reinterpret_cast<const f4*>(svz + o_own[k] + ((kd & kHasZp) ? row_z : 0));
+                f4 hy = *reinterpret_cast<const f4*>(svy + o_yp[k]);
+                f4 hz = *reinterpret_cast<const f4*>(svz + o_zp[k]);
                 if (k == 0) {
                     if (kd & kLastY) hy = gfy;
                     if (kd & kLastZ) hz = gfz;
