@@ -114,7 +114,8 @@ def test_iir_sequential_bit_exact_with_carried_state(gab, orc, T, B):
         assert orc.fnv_survey(orc.iir(x, c, st0, T, B)) == "fad0d0724cb98566"
 
 
-@pytest.mark.parametrize("T,B", [(128, 512), (3, 64), (1000, 128), (7, 1024), (130, 256)])
+@pytest.mark.parametrize("T,B", [(128, 512), (3, 64), (1000, 128), (7, 1024), (130, 256),
+                                 (16384, 512), (16387, 1024)])     # many tracks: the scan runs in 256-sample segments
 def test_iir_wave_scan_with_carried_state(gab, orc, T, B):
     """The wave-scan kernel re-associates the recurrence: gated at 1e-5 of peak
     (measured ~1e-7), outputs and carried state, over several buffers."""
