@@ -166,7 +166,10 @@ __global__ __launch_bounds__(kBlock) void modal_placeholder_kernel(const float* 
 // workgroups of ONE XCD (blocks b and b+8 share an XCD): they meet in that XCD's L2.
 // (Round 3, measured and not kept: 16-byte accesses — a lane reading four consecutive samples through
 // an unaligned dwordx4 load and storing four neighbouring tracks — 54.8 us against 46.5 at 65 536
-// tracks: the unaligned wide loads are split and cost more than the instructions they save.)
+// tracks: the unaligned wide loads are split and cost more than the instructions they save.  Wide STORES alone —
+// a 256-track x 64-sample tile written to LDS sample-major, each lane storing four neighbouring tracks, one
+// contiguous KiB per store instruction, loads as here — 66.5 us against 49.6 on the same box: the 66 KB tile
+// leaves 8 waves per CU where this kernel keeps 32, and the gather lives on waves in flight.)
 __global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict__ pool,
                                                        const int* __restrict__ playheads,
                                                        float* __restrict__ out, int T, int B) {
