@@ -541,7 +541,8 @@ constexpr int kResRowSlots = kResThreads / 32;      // a row of up to 128 cells 
 constexpr int kResRowDwords = 256;                  // one exchanged row: 128 granules {pressure, tag}
 #ifdef GAB_ABLATE
 constexpr unsigned kResSpinLimit = 1u << 13;        // diagnostic builds: give up after milliseconds (tools/fdtd_timeout_check.py)
-__device__ unsigned long long g_res_rounds[4];      // poll rounds, poll loops, clocks spent in the loops (one lane per wave counts)
+__device__ unsigned long long g_res_rounds[4];
+__device__ unsigned long long g_res_phase[16 * 8];  // [wave][mark]: clocks from the step's start to each mark, summed over steps (ablate bit 16, one workgroup)      // poll rounds, poll loops, clocks spent in the loops (one lane per wave counts)
 __device__ int g_res_ablate = 0;                    // 1 = no exchange between workgroups (wrong results); 2 = workgroup 0 never publishes
 #else
 constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling before giving up
@@ -712,8 +713,19 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         for (int st = 0; st < steps_per_sample; ++st, ++step) {
             const bool closes = st == steps_per_sample - 1;
             ++tag;
-            // ---- X, first half: ask for the neighbours' boundary quads of the previous step (stored at the head
-            // of its pressure phase, an interior row's worth of work ago); they are looked at after the faces below
+            // The order inside a step hides the hand-off's round trip (about 1.5 us from request to data) behind
+            // everything that does not need it — only the face rows' own pressures do:
+            //   ask | low faces of every row from the block's own pressures | barrier | pressures of the INTERIOR rows
+            //   | the quads that arrived -> the face rows' ghost-dependent faces -> their pressures, stored at once
+            //   | barrier
+#ifdef GAB_ABLATE
+            const bool stamping = (g_res_ablate & 16) && (tid & 63) == 0 && wg == (int)gridDim.x / 2 + 1;
+            const unsigned long long t_step = __builtin_amdgcn_s_memtime();
+#define GAB_RSTAMP(i) do { if (stamping) g_res_phase[(tid >> 6) * 8 + (i)] += __builtin_amdgcn_s_memtime() - t_step; } while (0)
+#else
+#define GAB_RSTAMP(i) do {} while (0)
+#endif
+            // ---- X, first half: ask for the neighbours' boundary quads of the previous step
             const bool odd = ((step - 1) & 1) != 0;
             const bool polls = step > 0 && !dead;
             const unsigned ay = polls ? get_y : kNowhere, az = polls ? get_z : kNowhere;
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
             // first row or plane, the row's first cell) reads its OWN pressure there: the difference is +0,
             // -c1 * +0 is -0 for c1 > 0 (checked by the host), and f + -0 = f for every f — the face keeps its
             // bits without a branch.  The rows that wait for a neighbour BLOCK's pressures do the same here and
-            // get their real update below, once those have arrived.
+            // get their real update below, once those have arrived (no other row reads those faces).
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 unsigned kd = kind[k];
@@ -740,7 +752,44 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 *reinterpret_cast<f4*>(svy + o_own[k]) = vy4[k];
                 *reinterpret_cast<f4*>(svz + o_own[k]) = vz4[k];
             }
+            GAB_RSTAMP(0);
+            __syncthreads();
+            GAB_RSTAMP(1);
+            // ---- P: pressure from the new faces
+            unsigned* const xb = xbuf + (step & 1) * parity_dwords;
+            auto pressure = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                unsigned kd = kind[k];
+                asm volatile("" : "+v"(kd));
+                const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
+                if (!(kd & kOn)) return;
+                f4 hy = *reinterpret_cast<const f4*>(svy + o_yp[k]);
+                f4 hz = *reinterpret_cast<const f4*>(svz + o_zp[k]);
+                if (k == 0) {
+                    if (kd & kLastY) hy = gfy;
+                    if (kd & kLastZ) hz = gfz;
+                }
+                const f4 pc = p4[k], fx = vx4[k];
+                const f4 div = (((f4){fx.y, fx.z, fx.w, fxn} - fx) + (hy - vy4[k])) + (hz - vz4[k]);
+                const f4 pin = __builtin_elementwise_fma((f4){-c2, -c2, -c2, -c2}, div, pc);
+                const f4 pd = pc * damp;
+                float pv[4] = {(kd & kM0) ? pin.x : pd.x, (kd & kM12) ? pin.y : pd.y, (kd & kM12) ? pin.z : pd.z,
+                               (kd & kM3) ? pin.w : pd.w};
+                if (closes && (kd >> kRcvShift) != 0) {                 // the receiver's or the source's quad (two lanes of the room)
+                    const int jr = (int)((kd >> kRcvShift) & 7u) - 1, js = (int)((kd >> kSrcShift) & 7u) - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j == jr) strip[smp] = __fmul_rn(pv[j], 0.1f);                       // FDTD3D_OUTPUT_SCALE
+                        if (j == js && smp + 1 < last) pv[j] = __fadd_rn(pv[j], inj[smp + 1]);
+                    }
+                }
+                p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
+                *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
+            };
+            // the interior rows first: they need nothing from outside the block
+            if constexpr (RPT > 1) pressure(std::integral_constant<int, 1>());
             __builtin_amdgcn_sched_barrier(0);
+            GAB_RSTAMP(2);
             // ---- X, second half: the granules' tags say whether they are that step's (no flag, no fence: guide
             // R2); a thread whose quads were not there yet asks again until they are
             if (polls) {
@@ -781,66 +830,32 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 }
 #endif
             }
-            // ---- V, the rows at the block's faces: the low faces that need the neighbour block's pressures, and
-            // the neighbour's low faces above the block's last row / plane (same operation, same operands as there)
+            GAB_RSTAMP(3);
+            // ---- V, the rows at the block's faces: the low faces that need the neighbour block's pressures (read
+            // by this row's own pressure only), and the neighbour's low faces above the block's last row / plane
+            // (same operation, same operands as there); then their pressures, stored at once
             {
                 unsigned kd = kind[0];
                 asm volatile("" : "+v"(kd));
                 if (kd & (kFirstY | kFirstZ | kLastY | kLastZ)) {
                     const f4 pc = p4[0];
-                    if (kd & kFirstY) {
-                        vy4[0] = fnma4(c1, pc, gpy, vy4[0]);
-                        *reinterpret_cast<f4*>(svy + o_own[0]) = vy4[0];
-                    }
-                    if (kd & kFirstZ) {
-                        vz4[0] = fnma4(c1, pc, gpz, vz4[0]);
-                        *reinterpret_cast<f4*>(svz + o_own[0]) = vz4[0];
-                    }
+                    if (kd & kFirstY) vy4[0] = fnma4(c1, pc, gpy, vy4[0]);
+                    if (kd & kFirstZ) vz4[0] = fnma4(c1, pc, gpz, vz4[0]);
                     if (kd & kLastY) gfy = fnma4(c1, gpy, pc, gfy);
                     if (kd & kLastZ) gfz = fnma4(c1, gpz, pc, gfz);
                 }
             }
-            __syncthreads();
-            // ---- P: pressure from the new faces; the face rows first, their quads stored write-through as they
-            // are made
-            unsigned* const xb = xbuf + (step & 1) * parity_dwords;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                unsigned kd = kind[k];
-                asm volatile("" : "+v"(kd));
-                const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
-                if (!(kd & kOn)) continue;
-                f4 hy = *reinterpret_cast<const f4*>(svy + o_yp[k]);
-                f4 hz = *reinterpret_cast<const f4*>(svz + o_zp[k]);
-                if (k == 0) {
-                    if (kd & kLastY) hy = gfy;
-                    if (kd & kLastZ) hz = gfz;
-                }
-                const f4 pc = p4[k], fx = vx4[k];
-                const f4 div = (((f4){fx.y, fx.z, fx.w, fxn} - fx) + (hy - vy4[k])) + (hz - vz4[k]);
-                const f4 pin = __builtin_elementwise_fma((f4){-c2, -c2, -c2, -c2}, div, pc);
-                const f4 pd = pc * damp;
-                float pv[4] = {(kd & kM0) ? pin.x : pd.x, (kd & kM12) ? pin.y : pd.y, (kd & kM12) ? pin.z : pd.z,
-                               (kd & kM3) ? pin.w : pd.w};
-                if (closes && (kd >> kRcvShift) != 0) {                 // the receiver's or the source's quad (two lanes of the room)
-                    const int jr = (int)((kd >> kRcvShift) & 7u) - 1, js = (int)((kd >> kSrcShift) & 7u) - 1;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (j == jr) strip[smp] = __fmul_rn(pv[j], 0.1f);                       // FDTD3D_OUTPUT_SCALE
-                        if (j == js && smp + 1 < last) pv[j] = __fadd_rn(pv[j], inj[smp + 1]);
-                    }
-                }
-                p4[k] = (f4){pv[0], pv[1], pv[2], pv[3]};
-                *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
-                if (k == 0) {
+            pressure(std::integral_constant<int, 0>());
 #ifdef GAB_ABLATE
-                    if ((g_res_ablate & 2) && wg == 0) continue;
+            if (!((g_res_ablate & 2) && wg == 0))
 #endif
-                    if (pub_y >= 0) publish_quad(xb + pub_y, p4[0], tag);
-                    if (pub_z >= 0) publish_quad(xb + pub_z, p4[0], tag);
-                }
+            {
+                if (pub_y >= 0) publish_quad(xb + pub_y, p4[0], tag);
+                if (pub_z >= 0) publish_quad(xb + pub_z, p4[0], tag);
             }
+            GAB_RSTAMP(4);
             __syncthreads();
+            GAB_RSTAMP(5);
         }
     }
     // ---- the block's fields go back to memory (the room's last faces never moved: they are still there)
@@ -1169,6 +1184,9 @@ int gab_fdtd_reset(gab_fdtd_plan* f, gab_stream_t stream) {
 #ifdef GAB_ABLATE
 extern "C" int gab_debug_fdtd_rounds(unsigned long long* h_out) {
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_res_rounds), sizeof(unsigned long long) * 4);
+}
+extern "C" int gab_debug_fdtd_phases(unsigned long long* h_out) {
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_res_phase), sizeof(unsigned long long) * 128);
 }
 #endif
 

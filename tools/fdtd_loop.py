@@ -39,3 +39,13 @@ if os.environ.get("GAB_FDTD_RES_ABLATE", "0") != "0" and hasattr(gab.lib, "gab_d
     if r[1]:
         print("resident kernel polls (one lane per wave): %.2f rounds per poll loop, %.0f clocks per loop, %.0f clocks draining the stores before it, %d loops"
               % (r[0] / r[1], r[2] / r[1], r[3] / r[1], r[1]))
+
+if os.environ.get("GAB_FDTD_RES_ABLATE", "0") != "0" and hasattr(gab.lib, "gab_debug_fdtd_phases"):
+    import ctypes
+    ph = (ctypes.c_ulonglong * 128)()
+    gab.lib.gab_debug_fdtd_phases(ph)
+    total_steps = steps * 4 + min(samples, 8) * 3          # every launch of this run added to the sums
+    if any(ph):
+        print("resident kernel, one workgroup, clocks from a step's start to: interior faces done | quads there | face rows done -> barrier A passed | pressures + stores done -> barrier B passed")
+        for w in range(16):
+            print("  wave %2d: " % w + "  ".join("%6.0f" % (ph[w * 8 + i] / total_steps) for i in range(6)))
