@@ -705,6 +705,9 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         return odd ? __builtin_amdgcn_raw_buffer_load_b128(xsrd1, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(xsrd0, off, 0, 16);
     };
 
+#ifdef GAB_ABLATE
+    unsigned phase_acc[6] = {0u, 0u, 0u, 0u, 0u, 0u};            // clocks from a step's start to each mark, summed in registers
+#endif
     unsigned tag = tag_base;
     bool dead = false;                                                  // a neighbour never arrived: stop waiting for good
     const int last = first_sample + n_samples;
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
 #ifdef GAB_ABLATE
             const bool stamping = (g_res_ablate & 16) && (tid & 63) == 0 && wg == (int)gridDim.x / 2 + 1;
             const unsigned long long t_step = __builtin_amdgcn_s_memtime();
-#define GAB_RSTAMP(i) do { if (stamping) g_res_phase[(tid >> 6) * 8 + (i)] += __builtin_amdgcn_s_memtime() - t_step; } while (0)
+#define GAB_RSTAMP(i) do { if (stamping) phase_acc[i] += (unsigned)(__builtin_amdgcn_s_memtime() - t_step); } while (0)
 #else
 #define GAB_RSTAMP(i) do {} while (0)
 #endif
@@ -858,6 +861,10 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
             GAB_RSTAMP(5);
         }
     }
+#ifdef GAB_ABLATE
+    if ((g_res_ablate & 16) && (tid & 63) == 0 && wg == (int)gridDim.x / 2 + 1)
+        for (int i = 0; i < 6; ++i) g_res_phase[(tid >> 6) * 8 + i] += phase_acc[i];
+#endif
     // ---- the block's fields go back to memory (the room's last faces never moved: they are still there)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {

@@ -46,6 +46,6 @@ if os.environ.get("GAB_FDTD_RES_ABLATE", "0") != "0" and hasattr(gab.lib, "gab_d
     gab.lib.gab_debug_fdtd_phases(ph)
     total_steps = steps * 4 + min(samples, 8) * 3          # every launch of this run added to the sums
     if any(ph):
-        print("resident kernel, one workgroup, clocks from a step's start to: interior faces done | quads there | face rows done -> barrier A passed | pressures + stores done -> barrier B passed")
+        print("resident kernel, one workgroup, clocks from a step's start to: low faces done | barrier A passed | interior pressures done | quads there | face rows + stores done | barrier B passed")
         for w in range(16):
             print("  wave %2d: " % w + "  ".join("%6.0f" % (ph[w * 8 + i] / total_steps) for i in range(6)))
