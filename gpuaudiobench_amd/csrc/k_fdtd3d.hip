@@ -551,6 +551,13 @@ constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling bef
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
+// the value of the lane before / after this one (whole-wave DPP shift: one VALU instruction, no LDS crossbar)
+__device__ __forceinline__ float lane_before(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));   // wave_shr:1
+}
+__device__ __forceinline__ float lane_after(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));   // wave_shl:1
+}
 __device__ __forceinline__ f4 fnma4(float c, f4 a, f4 b, f4 acc) {      // acc - c * (a - b): a rounded difference, then one fma
     const f4 d = a - b;                                                  // (vector forms: two floats per v_pk_* instruction)
     return __builtin_elementwise_fma((f4){-c, -c, -c, -c}, d, acc);
@@ -744,7 +751,7 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 unsigned kd = kind[k];
                 asm volatile("" : "+v"(kd));                        // re-derive the row's predicates here, not in 80 hoisted SGPRs
                 const f4 pc = p4[k];
-                float pl = __shfl_up(pc.w, 1);                          // the cell before the quad: the previous lane's last
+                float pl = lane_before(pc.w);                            // the cell before the quad: the previous lane's last
                 pl = x0 > 0 ? pl : pc.x;
                 if (!(kd & kOn)) continue;
                 const f4 pym = *reinterpret_cast<const f4*>(sp + o_ym[k]);
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 constexpr int k = decltype(kc)::value;
                 unsigned kd = kind[k];
                 asm volatile("" : "+v"(kd));
-                const float fxn = __shfl_down(vx4[k].x, 1);            // the face after the quad: the next lane's first
+                const float fxn = lane_after(vx4[k].x);                 // the face after the quad: the next lane's first
                 if (!(kd & kOn)) return;
                 f4 hy = *reinterpret_cast<const f4*>(svy + o_yp[k]);
                 f4 hz = *reinterpret_cast<const f4*>(svz + o_zp[k]);
