@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <string>
+#include <mutex>
 #include <utility>
 #include <algorithm>
 #include <vector>
@@ -986,6 +987,27 @@ gab::Fields virtual_base(const gab::Fields& real, const gab_fdtd_plan& pl) {
 
 // Blocks of nx x by x bz cells, one workgroup (one CU) each: the most workgroups the device can hold at once
 // whose LDS image fits, at most 64 rows per block (two per thread slot).
+// Two resident launches must not share the device: each needs every one of its workgroups on a CU at once, and
+// two half-placed grids would wait for each other until the polls time out.  Within this process they are chained:
+// a resident launch waits (on its own stream) for the previous one on the same device, whatever stream that was on.
+struct ResidentChain {
+    std::mutex mu;
+    hipEvent_t last[64] = {};
+    template <class Launch>
+    void run(hipStream_t q, Launch&& launch) {        // wait for the previous one, launch, leave the mark — one at a time
+        int dev = 0;
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        std::lock_guard<std::mutex> lock(mu);
+        if (known) {
+            if (last[dev]) (void)hipStreamWaitEvent(q, last[dev], 0);
+            else if (hipEventCreateWithFlags(&last[dev], hipEventDisableTiming) != hipSuccess) last[dev] = nullptr;
+        }
+        launch();
+        if (known && last[dev]) (void)hipEventRecord(last[dev], q);
+    }
+};
+ResidentChain g_resident_chain;
+
 void choose_resident_geometry(gab_fdtd_plan* f) {
     const gab_fdtd_params& P = f->P;
     f->res_rpt = 0;
@@ -1294,7 +1316,7 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
     gab::fdtd_resident_kernel<RPT><<<dim3(wgs), dim3(gab::kResThreads), f->res_lds_bytes, q>>>(                    \
         cur, g, f->rgeom, P.dt_over_rho_dx, P.rho_c2_dt_over_dx, 1.0f - P.absorption_coeff, src, rcv, f->inj, f->strip, \
         first_sample, n_samples, P.steps_per_sample, f->res_xbuf, f->res_tag, tmo)
-                if (f->res_rpt == 1) GAB_RESIDENT_LAUNCH(1); else GAB_RESIDENT_LAUNCH(2);
+                g_resident_chain.run(q, [&]() { if (f->res_rpt == 1) GAB_RESIDENT_LAUNCH(1); else GAB_RESIDENT_LAUNCH(2); });
 #undef GAB_RESIDENT_LAUNCH
                 f->res_tag += (unsigned)n_samples * (unsigned)P.steps_per_sample;
                 GAB_HIP_CHECK(hipMemcpyAsync(f->res_timeout_host, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, q));

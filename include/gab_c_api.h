@@ -215,7 +215,8 @@ int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
  * up to 8192 cells per compute unit: 128^3 on 256 CUs) runs a whole buffer in ONE launch with the fields
  * resident in LDS and registers, one block of rows per workgroup, the blocks' boundary pressures handed to the
  * neighbours through memory every step (same bits as the step kernels, 4x their speed at 128^3).  It needs
- * every workgroup on the device at once: a workgroup that waits about a second for a neighbour gives up, the
+ * every workgroup on the device at once (resident launches of one process are chained per device, whatever
+ * their streams; other processes' kernels are not known): a workgroup that waits about a second for a neighbour gives up, the
  * NEXT call returns GAB_ERR_RUNTIME and the plan uses the step kernels from then on.  Larger rooms, z-slabs,
  * per-track positions and calls inside a stream capture use the step kernels.
  * *resident = 1 when the next call (outside a capture) takes the resident form, *workgroups = its grid. */

@@ -663,6 +663,34 @@ def test_fdtd_resident_rooms(gab, orc, dims):
     plan.close()
 
 
+def test_fdtd_resident_launches_from_two_streams(gab, orc):
+    """Two plans whose resident launches each want (nearly) every CU, driven from two streams with no host
+    sync in between: the library chains resident launches on a device, so neither waits for workgroups the other
+    is keeping off the chip (which would end in the one-second poll timeout and an error)."""
+    import torch
+    n, T, B = 64, 2, 6
+    P, G = orc.fdtd_params(n), gab.fdtd_default_params(n)
+    x = orc.Rand(3).bipolar(T * B)
+    xd = dev(x)
+    plans = [gab.FdtdPlan(G), gab.FdtdPlan(G)]
+    assert all(p.resident()[0] for p in plans)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros(T * B, device="cuda") for _ in plans]
+    torch.cuda.synchronize()
+    for first, cnt in ((0, 2), (2, 1), (3, 3)):
+        for p, st, o in zip(plans, streams, outs):
+            with torch.cuda.stream(st):
+                p.process(xd, o, T, B, first, cnt)
+    torch.cuda.synchronize()
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+    for p, o in zip(plans, outs):
+        assert np.array_equal(bits(host(o)), bits(ref))
+        assert np.array_equal(bits(host(p.pressure()).ravel()), bits(grids[0]))
+        p.close()
+
+
 def test_fdtd_c4_grid_scaling_property(gab, orc):
     """BASELINE C4 (128^3): every operation of the scheme is linear and a factor 2 is exact in
     fp32, so doubling the input must double every output bit for bit, at full size."""
