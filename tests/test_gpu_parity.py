@@ -600,6 +600,33 @@ def test_dwg_audible_configuration(gab, orc, variant):
     assert np.abs(ry).max() > 0
 
 
+@pytest.mark.parametrize("variant", ["naive", "accel"])
+def test_dwg_mix_crowded_and_sparse_samples(gab, orc, variant):
+    """The ordered per-sample mix (sparse form, from 2 048 waveguides on): 2 700 waveguides, a third of them with the same short line and the same tap
+    phase — their samples collect far more contributions than one wavefront sorts (the scan takes those) — the
+    rest spread out (sorted lists of a few entries); samples nobody reaches stay zero.  Bit-exact with the
+    golden's waveguide-order sum over four buffers."""
+    import torch
+    n_wg, B, ML = 2700, 384, 2000
+    wg, x = orc.dwg_init(n_wg, B)
+    L = wg["length"].astype(np.int64)
+    same = np.arange(n_wg) % 3 == 0
+    wg["length"] = np.where(same, 96, L)
+    L = wg["length"].astype(np.int64)
+    wg["writePos"] = np.where(same, 10, (np.arange(n_wg) * 7) % L)
+    wg["inputTapPos"] = (wg["writePos"] + 3) % L
+    wg["outputTapPos"] = wg["inputTapPos"]
+    v = gab.DWG_NAIVE if variant == "naive" else gab.DWG_ACCEL
+    fwd_r, bwd_r = np.zeros(n_wg * ML, np.float32), np.zeros(n_wg * ML, np.float32)
+    fwd, bwd = torch.zeros(n_wg * ML, device="cuda"), torch.zeros(n_wg * ML, device="cuda")
+    for it in range(4):
+        y = host(gab.dwg(dev(wg.view(np.uint8)), fwd, bwd, dev(x), B, ML, out_tracks=n_wg, variant=v))
+        ry = orc.dwg(wg, fwd_r, bwd_r, x, B, ML, out_tracks=n_wg)
+        assert np.array_equal(bits(y), bits(ry)), it
+        assert np.array_equal(bits(host(fwd)), bits(fwd_r)), it
+    assert np.abs(ry).max() > 0 and np.count_nonzero(ry) > 10
+
+
 @pytest.mark.parametrize("n,T,B,samples", [(20, 4, 16, 16), (52, 128, 512, 24), (33, 3, 8, 8),
                                           (128, 16, 8, 6),       # C4's grid, a few samples (LDS-halo kernel, 32 x 8)
                                           (100, 3, 6, 6),        # 32 x 8 tiles with a partial last tile row
