@@ -718,6 +718,39 @@ def test_fdtd_resident_launches_from_two_streams(gab, orc):
         p.close()
 
 
+def test_fdtd_resident_beside_other_work(gab, orc):
+    """Uneven load: another stream streams half a gigabyte through the chip over and over while the resident
+    kernel runs, so its workgroups start at different times and wait for neighbours that are not on a CU yet.
+    The hand-off must deliver every word regardless (granule tags, bounded polls): bit-exact fields and output."""
+    import torch
+    n, T, B = 64, 2, 24
+    P, G = orc.fdtd_params(n), gab.fdtd_default_params(n)
+    x = orc.Rand(5).bipolar(T * B)
+    xd = dev(x)
+    plan = gab.FdtdPlan(G)
+    assert plan.resident()[0]
+    out = torch.zeros(T * B, device="cuda")
+    big = torch.ones(128 * 1024 * 1024, device="cuda")          # 512 MB
+    hog, work = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(hog):
+        for _ in range(60):
+            big.mul_(1.0000001)
+    with torch.cuda.stream(work):
+        for first, cnt in ((0, 8), (8, 8), (16, 8)):
+            plan.process(xd, out, T, B, first, cnt)
+    with torch.cuda.stream(hog):
+        for _ in range(20):
+            big.mul_(1.0000001)
+    torch.cuda.synchronize()
+    grids = orc.fdtd_grids(P)
+    ref = np.zeros(T * B, np.float32)
+    orc.fdtd(P, grids, x, ref, T, B, 0, B, fused=True)
+    assert np.array_equal(bits(host(out)), bits(ref))
+    assert np.array_equal(bits(host(plan.pressure()).ravel()), bits(grids[0]))
+    plan.close()
+
+
 def test_fdtd_c4_grid_scaling_property(gab, orc):
     """BASELINE C4 (128^3): every operation of the scheme is linear and a factor 2 is exact in
     fp32, so doubling the input must double every output bit for bit, at full size."""
