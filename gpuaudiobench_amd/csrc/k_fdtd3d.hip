@@ -398,7 +398,7 @@ template <int TY, int TZ, int S, int NT>
 __global__ __launch_bounds__(NT) void fdtd_sample_tile_kernel(
     Fields o, Fields n, Grid g, float c1, float c2, float damp, size_t src, size_t rcv,
     const float* __restrict__ add_next, float* __restrict__ strip_out) {
-    constexpr int BY = TY + 2 * S, BZ = TZ + 2 * S;
+    constexpr int BZ = TZ + 2 * S;
     constexpr int LZ = NT;                             // LDS plane pitch: every thread has a slot
     constexpr int PAD = 64;                            // front / back pad: the y-1 / y+1 reads of the edge rows stay inside
     __shared__ float sp[PAD + BZ * LZ + PAD];
@@ -504,31 +504,28 @@ __global__ __launch_bounds__(NT) void fdtd_sample_tile_kernel(
 
 // ---- the whole room resident in LDS: ONE launch per buffer ------------------------------------------------
 // 128^3 cells with their three face arrays are 33.75 MB; the chip has 256 x 160 KB = 40 MB of LDS.  The room is
-// cut into blocks of nx x BY x BZ cells, one workgroup (= one CU) each, which keeps its block's p, vx, vy, vz in
-// registers (a thread owns the same cells for the whole launch) and in LDS (where its neighbours inside the
-// block read them) for every step of the buffer; only the block's four pressure faces cross to the
-// neighbouring workgroups, once per step, through memory.  No field touches HBM between the first step of a
-// buffer and its last: a step costs LDS traffic and one neighbour hand-off instead of 67 MB through the
-// memory system and a kernel boundary.
+// cut into blocks of nx x BY x BZ cells, one 1024-thread workgroup (= one CU) each.  A thread owns the same one
+// or two rows x four cells for the whole launch: p, vx, vy, vz in registers; p, vy, vz also in LDS, where the
+// rows above and below inside the block read them; vx neighbours by a lane shift.  No field touches HBM between
+// the first step of a buffer and its last; only the blocks' boundary PRESSURES cross between workgroups, once per
+// step, through memory (DESIGN.md section 4a has the measurements and the history of the form).
 //
 // A step is the reference's two phases (velocity kernel, pressure kernel: cuda/bench_fdtd3d.cu:14-98) done in
-// place — the fused kernels above compute the same values (they recompute the high faces instead of reading
-// them), so the result is bit-identical to them and to the oracle:
-//   V: every low face from the old pressures: own p in registers, p(x-1), p(y-1), p(z-1) from LDS; the new
-//      faces go to LDS.  The block also keeps its two HIGH ghost faces (vy at y0+BY, vz at z0+BZ — its
-//      neighbours' low faces) and updates them itself with the same operation on the same operands, so
-//      velocities never cross workgroups;
-//   P: pressure from the new faces: own in registers, vx(x+1), vy(y+1), vz(z+1) from LDS; the receiver tap and
-//      the next sample's source add ride on the step that closes a sample, as in the fused kernels;
-//   X: the block's four boundary pressure faces are stored write-through (sc1), the workgroup's flag is
-//      raised (the step's number), the four neighbours' flags are polled, their faces loaded (sc1) into the
-//      ghost layers.  This is the hand-off form MI355X_MICROARCH.md lists as measured-valid on gfx950 (payload
-//      and flag sc1 / agent-scope, every storing wave drained and behind the workgroup's barrier before the
-//      flag, a workgroup barrier between the poll and every load, whole 128-byte lines per store instruction):
-//      no cache-wide fence, and nothing depends on where a workgroup runs.  The exchange buffers alternate
-//      with the step's parity; a neighbour cannot be more than one step apart.
-// Every workgroup must be resident at once: the grid is at most one workgroup per CU (158 KB of LDS each), and
-// every spin is bounded — on a timeout the kernel sets a word the host turns into an error.
+// place — the same values as the fused step kernels above, so bit-identical to them and to the oracle:
+//   V  every low face from the old pressures.  The faces on the block's first row / plane need the neighbour
+//      block's pressures; the block also keeps the neighbour's low faces above its LAST row / plane and advances
+//      them itself (same operation, same operands as the neighbour), so velocities never cross workgroups;
+//   P  pressure from the new faces; the receiver tap and the next sample's source add ride on the step that closes
+//      a sample, as in the fused kernels;
+//   X  the hand-off: every boundary pressure is an 8-byte granule {value, tag = global step number} written by one
+//      sc1 (write-through) store; the consumer is the very thread that needs the quad and sc1-loads it until its
+//      four tags are the step's (MI355X_MICROARCH.md, form R2: no flag, no fence).  Two buffers by step parity: a
+//      neighbour is never more than one step apart.  Tags go on across launches.
+// Order inside a step (see the loop): ask | V from own pressures | barrier | P of the interior rows | what arrived
+// -> the face rows' ghost-dependent faces -> their P, stored at once | barrier.  Face rows are every thread's
+// first row, interior rows its second.
+// Every workgroup must be on a CU at once: the grid is at most one workgroup per CU, and every poll is bounded —
+// on a timeout the kernel sets a word the host turns into an error and a fall-back to the step kernels.
 struct ResidentGeom {
     int by, bz;            // block extent in y and z (cells); x is the whole row
     int gy, gz;            // blocks along y and z
@@ -542,8 +539,8 @@ constexpr int kResRowSlots = kResThreads / 32;      // a row of up to 128 cells 
 constexpr int kResRowDwords = 256;                  // one exchanged row: 128 granules {pressure, tag}
 #ifdef GAB_ABLATE
 constexpr unsigned kResSpinLimit = 1u << 13;        // diagnostic builds: give up after milliseconds (tools/fdtd_timeout_check.py)
-__device__ unsigned long long g_res_rounds[4];
-__device__ unsigned long long g_res_phase[16 * 8];  // [wave][mark]: clocks from the step's start to each mark, summed over steps (ablate bit 16, one workgroup)      // poll rounds, poll loops, clocks spent in the loops (one lane per wave counts)
+__device__ unsigned long long g_res_rounds[4];      // [0] extra poll rounds, [1] polls (bit 4; one lane per wave of one workgroup counts)
+__device__ unsigned long long g_res_phase[16 * 8];  // [wave][mark]: clocks from a step's start to each mark, summed over steps (bit 16, one workgroup)
 __device__ int g_res_ablate = 0;                    // 1 = no exchange between workgroups (wrong results); 2 = workgroup 0 never publishes
 #else
 constexpr unsigned kResSpinLimit = 1u << 20;        // ~ a second of polling before giving up
@@ -571,22 +568,6 @@ __device__ __forceinline__ void publish_quad(unsigned* row, f4 p, unsigned tag) 
     const u4 b = {__float_as_uint(p.z), tag, __float_as_uint(p.w), tag};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:512 sc1"
                  ::"v"(row), "v"(a), "v"(b) : "memory");
-}
-// Both ghost quads of a thread in one burst (a row that needs only one, or none, reads its own slot for the
-// other): four loads in flight, one wait.
-__device__ __forceinline__ void fetch_quads(const unsigned* ry, const unsigned* rz, u4& y0, u4& y1, u4& z0, u4& z1) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                 "global_load_dwordx4 %1, %4, off offset:512 sc1\n\t"
-                 "global_load_dwordx4 %2, %5, off sc1\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:512 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(y0), "=&v"(y1), "=&v"(z0), "=&v"(z1) : "v"(ry), "v"(rz) : "memory");
-}
-__device__ __forceinline__ void fetch_quad(const unsigned* r, u4& q0, u4& q1) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                 "global_load_dwordx4 %1, %2, off offset:512 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(q0), "=&v"(q1) : "v"(r) : "memory");
 }
 __device__ __forceinline__ unsigned peek_sc1(const unsigned* p) {
     unsigned v;

@@ -37,8 +37,8 @@ if os.environ.get("GAB_FDTD_RES_ABLATE", "0") != "0" and hasattr(gab.lib, "gab_d
     r = (ctypes.c_ulonglong * 4)()
     gab.lib.gab_debug_fdtd_rounds(r)
     if r[1]:
-        print("resident kernel polls (one lane per wave): %.2f rounds per poll loop, %.0f clocks per loop, %.0f clocks draining the stores before it, %d loops"
-              % (r[0] / r[1], r[2] / r[1], r[3] / r[1], r[1]))
+        print("resident kernel polls (GAB_FDTD_RES_ABLATE=4; one lane per wave of one workgroup): %.2f extra rounds per poll, %d polls"
+              % (r[0] / r[1], r[1]))
 
 if os.environ.get("GAB_FDTD_RES_ABLATE", "0") != "0" and hasattr(gab.lib, "gab_debug_fdtd_phases"):
     import ctypes
