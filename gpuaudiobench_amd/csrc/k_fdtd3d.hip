@@ -588,9 +588,10 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
     const int y0 = bj * by, z0 = bk * bz;
     const bool has_ym = bj > 0, has_yp = bj + 1 < rg.gy, has_zm = bk > 0, has_zp = bk + 1 < rg.gz;
     // LDS images, [row = lz * by + ly][nx] each: what a thread's neighbours inside the block read
+    const int lp = 4 * rg.nq;                                          // LDS row pitch: the row padded to whole quads
     float* const sp = lds;
-    float* const svy = sp + rg.rows * nx;
-    float* const svz = svy + rg.rows * nx;
+    float* const svy = sp + rg.rows * lp;
+    float* const svz = svy + rg.rows * lp;
 
     const int tid = threadIdx.x;
     const int xq = tid & 31;                                           // quad within the row
@@ -609,8 +610,8 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
     enum : unsigned {
         kOn = 1u, kHasYm = 2u, kHasZm = 4u, kHasYp = 8u, kHasZp = 16u,       // the row exists; it has a neighbour row INSIDE the block
         kFirstY = 32u, kFirstZ = 64u, kLastY = 128u, kLastZ = 256u,           // a neighbour block supplies / wants this row
-        kM0 = 512u, kM12 = 1024u, kM3 = 2048u,                                // which cells of the quad are interior cells of the room
-        kRcvShift = 12, kSrcShift = 15                                        // 1 + j of the receiver / source cell (0: not here)
+        kM0 = 512u, kM1 = 1024u, kM2 = 2048u, kM3 = 4096u,                    // which cells of the quad are interior cells of the room
+        kRcvShift = 13, kSrcShift = 16                                        // 1 + j of the receiver / source cell (0: not here)
     };
     // Face rows are every thread's FIRST row (the host only takes geometries whose face rows fit the row slots):
     // the ghost state exists once per thread, not once per row.
@@ -632,6 +633,26 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         else if (q < n_face) { ly = by - 1; lz = 1 + q - 2 * by - (bz - 2); }
         else { const int i = q - n_face; ly = 1 + i % (by - 2); lz = 1 + i / (by - 2); }
     };
+    // a thread's quad of a global row: one 16-byte access when rows are multiples of four cells (every quad is then
+    // whole and aligned), cell by cell otherwise (entry and exit of the launch only; inside it rows are padded quads)
+    const bool whole_quads = (nx & 3) == 0;
+    const int my_cells = nx - x0 < 4 ? nx - x0 : 4;
+    auto ld = [&](const float* a) -> f4 {
+        if (whole_quads) return *reinterpret_cast<const f4*>(a);
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (my_cells > 0) v.x = a[0];
+        if (my_cells > 1) v.y = a[1];
+        if (my_cells > 2) v.z = a[2];
+        if (my_cells > 3) v.w = a[3];
+        return v;
+    };
+    auto st = [&](float* a, f4 v) {
+        if (whole_quads) { *reinterpret_cast<f4*>(a) = v; return; }
+        if (my_cells > 0) a[0] = v.x;
+        if (my_cells > 1) a[1] = v.y;
+        if (my_cells > 2) a[2] = v.z;
+        if (my_cells > 3) a[3] = v.w;
+    };
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int q = slot + kResRowSlots * k;
@@ -641,11 +662,11 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         const int y = y0 + ly, z = z0 + lz;
         const bool on = xq < rg.nq && q < rg.rows && y < ny && z < nz;
         const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
-        o_own[k] = r * nx + x0;
-        o_ym[k] = o_own[k] - (ly > 0 ? nx : 0);
-        o_zm[k] = o_own[k] - (lz > 0 ? by * nx : 0);
-        o_yp[k] = o_own[k] + (ly + 1 < by ? nx : 0);
-        o_zp[k] = o_own[k] + (lz + 1 < bz ? by * nx : 0);
+        o_own[k] = r * lp + x0;
+        o_ym[k] = o_own[k] - (ly > 0 ? lp : 0);
+        o_zm[k] = o_own[k] - (lz > 0 ? by * lp : 0);
+        o_yp[k] = o_own[k] + (ly + 1 < by ? lp : 0);
+        o_zp[k] = o_own[k] + (lz + 1 < bz ? by * lp : 0);
         const bool face = k == 0;                                      // (rows of the later slots are interior rows)
         const bool first_y = face && on && ly == 0 && has_ym, last_y = face && on && ly == by - 1 && has_yp;
         const bool first_z = face && on && lz == 0 && has_zm, last_z = face && on && lz == bz - 1 && has_zp;
@@ -656,25 +677,27 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         const bool row_interior = y > 0 && y < ny - 1 && z > 0 && z < nz - 1;
         unsigned kd = (on ? kOn : 0u) | (ly > 0 ? kHasYm : 0u) | (lz > 0 ? kHasZm : 0u) | (ly + 1 < by ? kHasYp : 0u) |
                       (lz + 1 < bz ? kHasZp : 0u) | (first_y ? kFirstY : 0u) | (first_z ? kFirstZ : 0u) |
-                      (last_y ? kLastY : 0u) | (last_z ? kLastZ : 0u) | (row_interior && x0 > 0 ? kM0 : 0u) |
-                      (row_interior ? kM12 : 0u) | (row_interior && x0 + 4 < nx ? kM3 : 0u);
+                      (last_y ? kLastY : 0u) | (last_z ? kLastZ : 0u) | (row_interior && x0 > 0 && x0 < nx - 1 ? kM0 : 0u) |
+                      (row_interior && x0 + 1 < nx - 1 ? kM1 : 0u) | (row_interior && x0 + 2 < nx - 1 ? kM2 : 0u) |
+                      (row_interior && x0 + 3 < nx - 1 ? kM3 : 0u);
         p4[k] = vx4[k] = vy4[k] = vz4[k] = (f4){0.f, 0.f, 0.f, 0.f};
         if (on) {
-            if (rcv >= pi && rcv < pi + 4) kd |= (unsigned)(rcv - pi + 1) << kRcvShift;
-            if (src >= pi && src < pi + 4) kd |= (unsigned)(src - pi + 1) << kSrcShift;
-            p4[k] = *reinterpret_cast<const f4*>(f.p + pi);
-            vx4[k] = *reinterpret_cast<const f4*>(f.vx + ((size_t)z * ny + y) * px + x0);
-            vy4[k] = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0);
-            vz4[k] = *reinterpret_cast<const f4*>(f.vz + pi);
-            if (first_y) gpy = *reinterpret_cast<const f4*>(f.p + pi - nx);
+            const size_t cells = (size_t)(nx - x0 < 4 ? nx - x0 : 4);  // a row that is no multiple of four ends in a part quad
+            if (rcv >= pi && rcv < pi + cells) kd |= (unsigned)(rcv - pi + 1) << kRcvShift;
+            if (src >= pi && src < pi + cells) kd |= (unsigned)(src - pi + 1) << kSrcShift;
+            p4[k] = ld(f.p + pi);
+            vx4[k] = ld(f.vx + ((size_t)z * ny + y) * px + x0);
+            vy4[k] = ld(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0);
+            vz4[k] = ld(f.vz + pi);
+            if (first_y) gpy = ld(f.p + pi - nx);
             if (last_y) {
-                gpy = *reinterpret_cast<const f4*>(f.p + pi + nx);
-                gfy = *reinterpret_cast<const f4*>(f.vy + ((size_t)z * (ny + 1) + y + 1) * nx + x0);
+                gpy = ld(f.p + pi + nx);
+                gfy = ld(f.vy + ((size_t)z * (ny + 1) + y + 1) * nx + x0);
             }
-            if (first_z) gpz = *reinterpret_cast<const f4*>(f.p + pi - sxy);
+            if (first_z) gpz = ld(f.p + pi - sxy);
             if (last_z) {
-                gpz = *reinterpret_cast<const f4*>(f.p + pi + sxy);
-                gfz = *reinterpret_cast<const f4*>(f.vz + pi + sxy);
+                gpz = ld(f.p + pi + sxy);
+                gfz = ld(f.vz + pi + sxy);
             }
             *reinterpret_cast<f4*>(sp + o_own[k]) = p4[k];
         }
@@ -765,7 +788,7 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
                 const f4 div = (((f4){fx.y, fx.z, fx.w, fxn} - fx) + (hy - vy4[k])) + (hz - vz4[k]);
                 const f4 pin = __builtin_elementwise_fma((f4){-c2, -c2, -c2, -c2}, div, pc);
                 const f4 pd = pc * damp;
-                float pv[4] = {(kd & kM0) ? pin.x : pd.x, (kd & kM12) ? pin.y : pd.y, (kd & kM12) ? pin.z : pd.z,
+                float pv[4] = {(kd & kM0) ? pin.x : pd.x, (kd & kM1) ? pin.y : pd.y, (kd & kM2) ? pin.z : pd.z,
                                (kd & kM3) ? pin.w : pd.w};
                 if (closes && (kd >> kRcvShift) != 0) {                 // the receiver's or the source's quad (two lanes of the room)
                     const int jr = (int)((kd >> kRcvShift) & 7u) - 1, js = (int)((kd >> kSrcShift) & 7u) - 1;
@@ -862,10 +885,10 @@ __global__ __launch_bounds__(kResThreads, 1) void fdtd_resident_kernel(
         row_of(slot + kResRowSlots * k, ly, lz);
         const int y = y0 + ly, z = z0 + lz;
         const size_t pi = (size_t)z * sxy + (size_t)y * nx + x0;
-        *reinterpret_cast<f4*>(f.p + pi) = p4[k];
-        *reinterpret_cast<f4*>(f.vx + ((size_t)z * ny + y) * px + x0) = vx4[k];
-        *reinterpret_cast<f4*>(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0) = vy4[k];
-        *reinterpret_cast<f4*>(f.vz + pi) = vz4[k];
+        st(f.p + pi, p4[k]);
+        st(f.vx + ((size_t)z * ny + y) * px + x0, vx4[k]);
+        st(f.vy + ((size_t)z * (ny + 1) + y) * nx + x0, vy4[k]);
+        st(f.vz + pi, vz4[k]);
     }
 }
 
@@ -992,7 +1015,7 @@ ResidentChain g_resident_chain;
 void choose_resident_geometry(gab_fdtd_plan* f) {
     const gab_fdtd_params& P = f->P;
     f->res_rpt = 0;
-    if (f->z_begin != 0 || f->z_end != P.nz || (P.nx & 3) || P.nx > 128 || P.nx < 8) return;
+    if (f->z_begin != 0 || f->z_end != P.nz || P.nx > 128) return;
     if (!(P.dt_over_rho_dx > 0.0f)) return;                      // the kernel's branch-free boundary faces need -c1 * 0 = -0
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
@@ -1006,13 +1029,13 @@ void choose_resident_geometry(gab_fdtd_plan* f) {
             if (rows > gab::kResRowSlots && 2 * (by + bz) - 4 > gab::kResRowSlots) continue;   // face rows: every thread's first row
             const long gy = (P.ny + by - 1) / by, gz = (P.nz + bz - 1) / bz, w = gy * gz;
             if (w > cus || w < 2) continue;
-            const size_t floats = (size_t)3 * rows * P.nx;                  // p, vy, vz images
+            const size_t floats = (size_t)3 * rows * (size_t)((P.nx + 3) / 4 * 4);   // p, vy, vz images, rows padded to whole quads
             if (floats * sizeof(float) + 64 > (size_t)lds_max) continue;
             const long surface = by + bz;                       // exchanged rows per block ~ 2 (by + bz)
             if (w > best_w || (w == best_w && surface < best_surface)) {
                 best_w = w;
                 best_surface = surface;
-                f->rgeom = gab::ResidentGeom{by, bz, (int)gy, (int)gz, P.nx / 4, rows, by > bz ? by : bz};
+                f->rgeom = gab::ResidentGeom{by, bz, (int)gy, (int)gz, (P.nx + 3) / 4, rows, by > bz ? by : bz};
                 f->res_rpt = (rows + gab::kResRowSlots - 1) / gab::kResRowSlots;
                 f->res_lds_bytes = floats * sizeof(float);
             }

@@ -211,7 +211,7 @@ int gab_fdtd_reset(gab_fdtd_plan* plan, gab_stream_t stream);     /* zero grids 
 int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
                      int tracks, int bufsize, int first_sample, int n_samples,
                      gab_stream_t stream);
-/* Which form gab_fdtd_process takes.  A room whose four fields fit the chip's LDS (nx a multiple of 4, 8..128;
+/* Which form gab_fdtd_process takes.  A room whose four fields fit the chip's LDS (nx <= 128;
  * up to 8192 cells per compute unit: 128^3 on 256 CUs) runs a whole buffer in ONE launch with the fields
  * resident in LDS and registers, one block of rows per workgroup, the blocks' boundary pressures handed to the
  * neighbours through memory every step (same bits as the step kernels, 4x their speed at 128^3).  It needs

@@ -646,8 +646,8 @@ def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     grids = orc.fdtd_grids(P)
     ref = np.zeros(T * B, np.float32)
     plan = gab.FdtdPlan(G)
-    # rows of 4..128 cells in multiples of four whose fields fit the LDS take the resident whole-buffer kernel
-    assert plan.resident()[0] == (n in (20, 52, 128, 100))
+    # rooms up to 128 cells wide whose fields fit the LDS take the resident whole-buffer kernel
+    assert plan.resident()[0] == (n <= 128)
     out = torch.zeros(T * B, device="cuda")
     half = samples // 2
     for first, cnt in ((0, half), (half, samples - half)):       # state carries across calls
@@ -661,10 +661,12 @@ def test_fdtd_bit_exact(gab, orc, n, T, B, samples):
     plan.close()
 
 
-@pytest.mark.parametrize("dims", [(8, 6, 5), (24, 21, 19), (64, 30, 9), (128, 5, 7), (12, 64, 64), (128, 40, 50)])
+@pytest.mark.parametrize("dims", [(8, 6, 5), (24, 21, 19), (64, 30, 9), (128, 5, 7), (12, 64, 64), (128, 40, 50),
+                                  (50, 21, 19), (7, 9, 11), (127, 6, 5), (5, 4, 4), (33, 40, 12)])    # rows that end in a part quad
 def test_fdtd_resident_rooms(gab, orc, dims):
     """The LDS-resident kernel on rooms that are not cubes: blocks that do not divide the room (a clipped last
-    block in y and in z), one-quad and full-width rows, more workgroups along one axis than the other; several
+    block in y and in z), one-quad and full-width rows, rows that are no multiple of four cells (the last quad
+    is partly padding), more workgroups along one axis than the other; several
     calls in a row (the exchange tags go on across launches), a reset in between, source and receiver placed by
     the reference's proportions.  Bit for bit the oracle's fields and outputs."""
     import torch
