@@ -97,6 +97,7 @@ PROTOTYPES = {
     "gab_conv_set_scheme": (_I, [_P, _I]),
     "gab_conv_get_scheme": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_process_batch": (_I, [_P, _P, _P, _I, _P]),
+    "gab_conv_round_trip": (_I, [_P, _P, _P, _P]),
     "gab_conv_state_bytes": (_I, [_P, C.POINTER(_Z), C.POINTER(_Z)]),
     "gab_fdtd_default_params": (_I, [_I, _I, _I, C.POINTER(FdtdParams)]),
     "gab_fdtd_create": (_I, [C.POINTER(_P), C.POINTER(FdtdParams)]),

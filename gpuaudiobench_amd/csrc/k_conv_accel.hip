@@ -35,6 +35,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -581,6 +582,212 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
     conv_split_buffer(in, out, hist, pmA, sp, tw, T, head, lds);
 }
 
+// ---- the real-time round trip: one buffer, pinned host in -> pinned host out, both link directions busy at once ----
+// gab_conv_round_trip (classic cut).  What crosses the link is 2 MiB each way at C3; the reference moves them one after
+// the other around its kernels (cuda/bench_base.cu:30-42, bench_conv1d_accel.cu:258-304).  Measured on this part
+// (tools/ubench/link_duplex, link_modes): a kernel reads pinned memory at 50 GB/s and writes it at 51 GB/s, but doing
+// both at once it gets 27-29 GB/s each way; a copy-engine upload beside a kernel that writes pinned memory runs both at
+// full rate; every extra engine copy costs ~10 us.  Hence:
+//   up    ONE engine copy of the whole input into `stage` (fine-grained device memory, so that a running kernel sees
+//         it land), on the plan's own stream, started before the kernel;
+//   wait  the kernel is launched at once: every workgroup (one channel pair) first runs the far partition — taps
+//         [512,4096) see the eight PREVIOUS blocks only — and then polls for its two rows.  A consumed word is
+//         overwritten with a sentinel (a NaN no audio stream carries), so "my words are no longer the sentinel" means
+//         they have landed; a buffer that really holds the sentinel is released by the `landed` word the host sets
+//         once the copy's event has completed — slower, never wrong;
+//   down  outputs are parked sample-major in device memory by write-through stores; the workgroup whose arrival
+//         completes a channel group (the copy lands groups in order) drains the group's slab to the pinned output in
+//         whole rows of the group's width, so the link carries 256-512-byte pieces while later groups are still landing;
+//   done  the drain that completes the last group writes the epoch to a pinned word the host is spinning on.
+// Same operations in the same order as conv_overlap_save_kernel<true, true>: bit-identical to device-buffer launches.
+constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
+constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
+struct ConvRoundTrip {
+    unsigned* stage;                  // [T*B] fine-grained device memory
+    float* park;                      // [B*T] device memory
+    float* h_out;                     // [B*T] pinned host memory
+    unsigned* counters;               // device: [g] arrivals of group g, [groups] groups drained
+    unsigned* done;                   // pinned host: the epoch, once h_out is complete
+    const unsigned* landed;           // pinned host: the epoch, once the host has seen the upload complete
+    unsigned* error;                  // pinned host: nonzero if a wait ran out
+    unsigned epoch;
+    int pairs_per_group, groups;
+};
+
+__device__ __forceinline__ unsigned rt_peek(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
+    ConvRoundTrip rt, float* __restrict__ hist, const float4* __restrict__ pmA, const float4* __restrict__ pmB,
+    const cf* __restrict__ tw, int T, int head) {
+    __shared__ cf lds[2 * kLdsHalf];
+    __shared__ int s_word;
+    cf* const lds0 = lds;
+    cf* const lds1 = lds + kLdsHalf;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;                       // pairs in dispatch order: the copy lands them in that order too
+    const int ta = 2 * q;
+    cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+    using FA = fft::BlockFFT<kNA, 4, false>;
+    using FAi = fft::BlockFFT<kNA, 4, true>;
+    using FB = fft::BlockFFT<kNB, 16, false>;
+    using FBi = fft::BlockFFT<kNB, 16, true>;
+
+    // ---- far partition: blocks k-8 .. k-1, oldest first (slot `head` holds the oldest until the new block replaces it)
+    cf zb[16];
+    typename FB::Bases twb_base;
+    FB::load_twiddles(twb_base, tw, tid);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zb[r] = hp[((head + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + tid];
+    const cf prev0 = zb[14], prev1 = zb[15];        // block k-1: the near window's first half
+    {
+        float4 cb[16];
+        load_spectra<kNB, 16>(cb, pmB + (size_t)q * kBinsB, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        typename FB::Twiddles twb;
+        FB::expand_twiddles(twb_base, twb);
+        FB::run(zb, lds1, lds0, twb, tid);
+        cf zpb[16];
+        partner_exchange<kNB, 16, true>(zb, zpb, lds1, tid);
+        spectral_product<kNB, 16>(zb, zpb, cb, tid);
+        FBi::template run<typename FB::Twiddles, 2>(zb, lds0, lds1, twb, tid);      // only [14], [15]
+    }
+    const cf far0 = zb[14], far1 = zb[15];
+
+    // ---- the pair's two rows: wait until they have landed
+    const unsigned* const row = rt.stage + (size_t)ta * kB;                         // 2 x 512 words, contiguous
+    if (tid == 0) {
+        int tries = 0, bad = 0;
+        while (rt_peek(row + 2 * kB - 1) == kRtSentinel) {                          // the region's last word
+            // (a pinned word: looked at every 64th round only — 512 pollers reading it every round would be link traffic)
+            if ((++tries & 63) == 0 && rt_peek(rt.landed) == rt.epoch) break;       // the whole upload is in: it IS the sentinel
+            if (tries > kRtPollLimit) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(30);
+        }
+        s_word = bad;
+    }
+    __syncthreads();
+    bool gave_up = s_word != 0;
+    unsigned w[4];
+    {
+        int tries = 0;
+        for (;;) {
+            w[0] = rt_peek(row + tid);
+            w[1] = rt_peek(row + tid + kThreads);
+            w[2] = rt_peek(row + kB + tid);
+            w[3] = rt_peek(row + kB + tid + kThreads);
+            if (gave_up || (w[0] != kRtSentinel && w[1] != kRtSentinel && w[2] != kRtSentinel && w[3] != kRtSentinel)) break;
+            if ((++tries & 15) == 0 && rt_peek(rt.landed) == rt.epoch) {            // landed for good: one more look, then take it
+                w[0] = rt_peek(row + tid);
+                w[1] = rt_peek(row + tid + kThreads);
+                w[2] = rt_peek(row + kB + tid);
+                w[3] = rt_peek(row + kB + tid + kThreads);
+                break;
+            }
+            if (tries > kRtPollLimit) { gave_up = true; break; }
+            __builtin_amdgcn_s_sleep(10);
+        }
+    }
+    if (gave_up) __hip_atomic_store(rt.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the words are taken: the sentinel goes back for the next buffer (complete before this launch ends)
+    __hip_atomic_store(const_cast<unsigned*>(row) + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(const_cast<unsigned*>(row) + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
+    // ---- near partition: [block k-1 | block k]
+    cf za[4];
+    za[0] = prev0;
+    za[1] = prev1;
+    za[2] = mk(__uint_as_float(w[0]), __uint_as_float(w[2]));
+    za[3] = mk(__uint_as_float(w[1]), __uint_as_float(w[3]));
+    float4 ca[4];
+    load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
+    typename FA::Twiddles twa;
+    {
+        typename FA::Bases twa_base;
+        FA::load_twiddles(twa_base, tw, tid);
+        FA::expand_twiddles(twa_base, twa);
+    }
+    hp[head * kB + tid] = za[2];                     // the new block replaces the oldest
+    hp[head * kB + kThreads + tid] = za[3];
+    __syncthreads();                                 // the far partition's last LDS readers are done
+    FA::run(za, lds0, lds1, twa, tid);
+    {
+        cf zpa[4];
+        partner_exchange<kNA, 4, true>(za, zpa, lds0, tid);
+        spectral_product<kNA, 4>(za, zpa, ca, tid);
+    }
+    FAi::run(za, lds1, lds0, twa, tid);
+    float ya0 = 0.f, yb0 = 0.f, ya1 = 0.f, yb1 = 0.f;           // the sums in conv_one_buffer's order: (0 + near) + far
+    ya0 += za[2].x; yb0 += za[2].y; ya1 += za[3].x; yb1 += za[3].y;
+    ya0 += far0.x; yb0 += far0.y; ya1 += far1.x; yb1 += far1.y;
+
+    // ---- park (write-through, so that the draining workgroup, on whatever XCD, finds it in memory)
+    {
+        unsigned long long* const p0 = reinterpret_cast<unsigned long long*>(rt.park + (size_t)T * tid + ta);
+        unsigned long long* const p1 = reinterpret_cast<unsigned long long*>(rt.park + (size_t)T * (tid + kThreads) + ta);
+        const unsigned long long v0 = ((unsigned long long)__float_as_uint(yb0) << 32) | __float_as_uint(ya0);
+        const unsigned long long v1 = ((unsigned long long)__float_as_uint(yb1) << 32) | __float_as_uint(ya1);
+        __hip_atomic_store(p0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its own stores
+    __syncthreads();
+    const int g = q / rt.pairs_per_group;
+    const int first = g * rt.pairs_per_group;
+    const int members = min(rt.pairs_per_group, (int)gridDim.x - first);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&rt.counters[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_word = (old + 1u == rt.epoch * (unsigned)members) ? 1 : 0;       // counters run on from launch to launch (mod 2^32)
+        if (s_word) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate completes asynchronously
+        }
+    }
+    __syncthreads();
+    if (s_word == 0) return;
+
+    // ---- the group is complete: its slab, rows of `members` pairs, goes to the pinned output
+    {
+        const int row_f4 = members / 2;                          // float4 per row (members is even: T % 4 == 0)
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc(rt.park, 0, (int)((size_t)T * kB * 4), 0x00020000);
+        const int total = kB * row_f4;                           // float4 of the slab
+        const int col0 = 2 * first;
+        for (int base = 0; base < total; base += 8 * kThreads) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * kThreads + tid;
+                const int sidx = i / row_f4, c = i - sidx * row_f4;
+                const unsigned off = i < total ? 4u * (unsigned)(T * sidx + col0 + 4 * c) : 0xfffffff0u;   // out of range: dropped
+                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, off, 0, 16);                   // sc1
+                v[u] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * kThreads + tid;
+                const int sidx = i / row_f4, c = i - sidx * row_f4;
+                if (i < total) {                                  // system-scope write-through: nothing of it stays behind in a cache
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v val = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    float* const dst = rt.h_out + (size_t)T * sidx + col0 + 4 * c;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
+                }
+            }
+        }
+    }
+    // every wave waits for its own rows to be accepted by the link's ordered queue, THEN the group counts as drained;
+    // the launch's last drain therefore issues the completion word behind every row of every group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&rt.counters[rt.groups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == rt.epoch * (unsigned)rt.groups) __hip_atomic_store(rt.done, rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // The launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup walks them
 // in order for its pair.  Pairs are independent, so nothing is synchronised between workgroups; a
 // thread re-reads from the ring only what it wrote itself; the LDS hand-over rule of the stages
@@ -667,6 +874,9 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         FB::load_twiddles(twb, tw, ft);
         // (Measured, not kept: the next buffer's 36 requests spread over three barrier intervals instead of
         // one burst after the spectral product — the burst's 0.6 us on the chain only moves: 5.75 vs 5.31 us.)
+        // Blocks that lie inside the launch come from the input buffers (block k-j = buffer nb-j), older ones
+        // from the history ring as the previous launch left it: the ring is neither read nor written in the
+        // steady state of a launch (the forward waves refresh it over the launch's last eight buffers).
         auto load_window = [&](int nb, cf (&z)[16], float4 (&c)[16]) {
             const int head = (head0 + nb) & (kSlots - 1);
             const int q = 2 * d + (head & 1);
@@ -675,18 +885,27 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             const float* const cur = in + nb * step;
             z[14] = mk(cur[ca + ft], cur[cb_ + ft]);
             z[15] = mk(cur[ca + ft + kThreads], cur[cb_ + ft + kThreads]);
-            if (nb > 0) {                                             // block k-1 = the previous input buffer
-                const float* const prv = cur - step;
-                z[12] = mk(prv[ca + ft], prv[cb_ + ft]);
-                z[13] = mk(prv[ca + ft + kThreads], prv[cb_ + ft + kThreads]);
-            } else {
-                const int s = ((head + kSlots - 1) & (kSlots - 1)) * kB;
-                z[12] = hp[s + ft];
-                z[13] = hp[s + kThreads + ft];
-            }
+            if (nb >= kSlots - 1) {                                   // the whole window lies inside the launch
 #pragma unroll
-            for (int r = 0; r < 12; ++r)                              // blocks k-7 .. k-2
-                z[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
+                for (int bl = 0; bl < 7; ++bl) {
+                    const float* const src = cur - (size_t)(7 - bl) * step;
+                    z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
+                    z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
+                }
+            } else {
+#pragma unroll
+                for (int bl = 0; bl < 7; ++bl) {                      // block k-7+bl = buffer nb-7+bl (uniform branch)
+                    if (nb - 7 + bl >= 0) {
+                        const float* const src = cur - (size_t)(7 - bl) * step;
+                        z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
+                        z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
+                    } else {
+                        const int s = ((head + 1 + bl) & (kSlots - 1)) * kB;
+                        z[2 * bl] = hp[s + ft];
+                        z[2 * bl + 1] = hp[s + kThreads + ft];
+                    }
+                }
+            }
             load_spectra<kNB, 16>(c, sp.pmF + (size_t)q * kBinsB, ft);
         };
         cf zb[16], zn[16];
@@ -792,8 +1011,10 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             __syncthreads();                                          // barrier 1
 #pragma unroll
             for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
+            if (nb + kSlots >= n_buffers) {                           // the ring only has to hold the launch's LAST eight blocks
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];     // the new block enters the ring
+                for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
             if (nb + 1 < n_buffers) {                                 // the next buffer's block: needed a period from now
@@ -1225,6 +1446,16 @@ struct gab_conv_plan {
     gab::fft::cf* carry = nullptr;
     size_t carry_bytes = 0;
     bool fresh = true;        // nothing has run since the last reset
+    // gab_conv_round_trip (classic cut): created at its first call
+    unsigned* rt_stage = nullptr;       // fine-grained device memory the upload lands in
+    float* rt_park = nullptr;           // device: outputs until their channel group is complete
+    unsigned* rt_counters = nullptr;    // device: per-group arrivals, groups drained
+    unsigned* rt_words = nullptr;       // pinned host: [0] done, [16] landed, [32] error (a 64-byte line each)
+    hipStream_t rt_copy_stream = nullptr;
+    hipEvent_t rt_copy_ev = nullptr;
+    unsigned rt_epoch = 0;
+    int rt_groups = 0, rt_pairs_per_group = 0;
+    const void* rt_checked_out = nullptr;
     // uniform partitions (conv_uniform_kernel): other power-of-two buffer sizes / longer responses
     bool uniform = false;
     int uJ = 0, uS = 0, ring_len = 0;
@@ -1336,6 +1567,12 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->pmU) (void)hipFree(p->pmU);
     if (p->ring) (void)hipFree(p->ring);
     if (p->reset_ev) (void)hipEventDestroy(p->reset_ev);
+    if (p->rt_stage) (void)hipFree(p->rt_stage);
+    if (p->rt_park) (void)hipFree(p->rt_park);
+    if (p->rt_counters) (void)hipFree(p->rt_counters);
+    if (p->rt_words) (void)hipHostFree(p->rt_words);
+    if (p->rt_copy_ev) (void)hipEventDestroy(p->rt_copy_ev);
+    if (p->rt_copy_stream) (void)hipStreamDestroy(p->rt_copy_stream);
     delete p;
     return GAB_OK;
 }
@@ -1489,6 +1726,89 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
             }
             int rc = gab::launch_status("conv_direct_kernel");
             if (rc) return rc;
+        }
+        return GAB_OK;
+    });
+}
+
+// The staging buffers, counters and the upload stream of gab_conv_round_trip.
+static void gab_conv_round_trip_init(gab_conv_plan* p) {
+    const size_t n = (size_t)p->tracks * p->bufsize;
+    GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->rt_stage), n * 4, hipDeviceMallocFinegrained));
+    GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, n));
+    GAB_HIP_CHECK(hipMalloc(&p->rt_park, n * 4));
+    int groups = 16;                                  // 64 channels = 256-byte rows at 1024 channels
+#ifdef GAB_ABLATE
+    if (getenv("GAB_RT_GROUPS")) groups = std::max(1, atoi(getenv("GAB_RT_GROUPS")));
+#endif
+    int ppg = (p->pairs + groups - 1) / groups;
+    ppg += ppg & 1;                                   // whole float4 columns per row
+    p->rt_pairs_per_group = ppg;
+    p->rt_groups = (p->pairs + ppg - 1) / ppg;
+    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * (p->rt_groups + 1)));
+    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * (p->rt_groups + 1)));
+    GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
+    for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
+    GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
+    GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_copy_ev, hipEventDisableTiming));
+    GAB_HIP_CHECK(hipDeviceSynchronize());
+    p->rt_epoch = 0;
+}
+
+int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!p || !h_in || !h_out) return gab::bad_arg("gab_conv_round_trip: null argument");
+        if (!p->ir_set) return gab::bad_arg("gab_conv_round_trip: gab_conv_set_ir has not been called");
+        hipStream_t s = gab::as_stream(stream);
+        if (!(p->fused && p->tail && !p->split && (p->tracks % 4) == 0)) {
+            // every other plan: the kernel moves the buffers over the link itself (h_in must then be pinned too)
+            int rc = gab_conv_process(p, h_in, h_out, GAB_CONV_STREAMING_HOST_IO, stream);
+            if (rc) return rc;
+            GAB_HIP_CHECK(hipStreamSynchronize(s));
+            return GAB_OK;
+        }
+        if (!p->rt_stage) gab_conv_round_trip_init(p);
+        if (p->rt_checked_out != h_out) {              // the kernel writes h_out itself: it must be mapped into the device
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, h_out) != hipSuccess || at.devicePointer == nullptr) {
+                (void)hipGetLastError();
+                return gab::bad_arg("gab_conv_round_trip: h_out must be pinned host memory (hipHostMalloc) or device memory");
+            }
+            p->rt_checked_out = h_out;
+        }
+        p->order_after_reset(s);
+        const size_t bytes = sizeof(float) * (size_t)p->tracks * p->bufsize;
+        const unsigned epoch = ++p->rt_epoch;
+        volatile unsigned* const done = p->rt_words;
+        volatile unsigned* const landed = p->rt_words + 16;
+        volatile unsigned* const error = p->rt_words + 32;
+        GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+        gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
+                              epoch, p->rt_pairs_per_group, p->rt_groups};
+        gab::conv_round_trip_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(rt, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
+        int rc = gab::launch_status("conv_round_trip_kernel");
+        GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
+        p->head = (p->head + 1) & (gab::kSlots - 1);
+        p->fresh = false;
+        if (rc) return rc;
+        // the pinned word says the output is complete; the upload's event releases workgroups whose rows really
+        // hold the sentinel
+        bool told = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*done != epoch) {
+            if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) { *landed = epoch; told = true; }
+            if ((++spins & 1023u) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+                gab::set_last_error("gab_conv_round_trip: the launch did not complete within 4 s");
+                return GAB_ERR_RUNTIME;
+            }
+        }
+        if (!told) *landed = epoch;
+        if (*error != 0) {
+            *error = 0;
+            gab::set_last_error("gab_conv_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
+            return GAB_ERR_RUNTIME;
         }
         return GAB_OK;
     });

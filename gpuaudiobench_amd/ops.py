@@ -173,6 +173,26 @@ class ConvPlan:
         check(lib.gab_conv_process(self._h, _acc(x), _acc(out), mode, _stream()))
         return out
 
+    def round_trip(self, h_in, h_out, stream=None):
+        """One buffer, pinned host tensor in -> pinned host tensor out; returns when h_out is complete
+        (gab_conv_round_trip)."""
+        assert h_in.numel() == self.tracks * self.bufsize == h_out.numel()
+        if h_in.is_cuda or h_out.is_cuda or not h_out.is_pinned():
+            raise TypeError("round_trip takes host tensors; the output must be pinned")
+        if h_in.dtype != torch.float32 or h_out.dtype != torch.float32 or not h_in.is_contiguous() or not h_out.is_contiguous():
+            raise TypeError("round_trip takes contiguous float32 tensors")
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        check(lib.gab_conv_round_trip(self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr()), st))
+        return h_out
+
+    def prepare_round_trip(self, h_in, h_out, stream=None):
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        return (self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr()), st)
+
+    @staticmethod
+    def launch_round_trip(args):
+        check(lib.gab_conv_round_trip(*args))
+
     def process_batch(self, x, n_buffers, out=None):
         """n_buffers consecutive buffers ([n][T*B] in, [n][B*T] out) in one launch."""
         assert x.numel() == n_buffers * self.tracks * self.bufsize

@@ -183,6 +183,17 @@ int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
  * iteration.                                                                     */
 int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
                            int n_buffers, gab_stream_t stream);
+/* One buffer from pinned host memory to pinned host memory, returning when h_out holds the result — the
+ * reference's whole iteration (transferToDevice, the pipeline, transferToHost: cuda/bench_base.cu:30-42 +
+ * bench_conv1d_accel.cu:258-304) with both link directions busy at once.  Streaming mode, same state and same
+ * bits as gab_conv_process on device buffers.  On a CLASSIC-cut plan (512-sample buffers, 513..4096 taps,
+ * channel count divisible by 4) the upload is one engine copy into a staging buffer that the kernel — launched
+ * at once, its history-only partition first — consumes as it lands, and the outputs go back in channel groups
+ * while later groups are still arriving (conv_round_trip_kernel).  Other plans: the kernel moves both buffers
+ * over the link itself (as GAB_CONV_STREAMING_HOST_IO; h_in must then be pinned as well) and the call waits
+ * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  Blocking; one call at a time
+ * per plan.  GAB_ERR_RUNTIME if the input never arrived (the output of that call is then invalid).       */
+int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
                          size_t* history_bytes);

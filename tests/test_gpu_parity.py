@@ -343,6 +343,99 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
         b.close()
 
 
+@pytest.mark.parametrize("T,L,n", [(64, 4096, 12), (1024, 4096, 12), (8, 1500, 10), (2052, 3000, 3), (8192, 4096, 2)])
+def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, orc, T, L, n):
+    """gab_conv_round_trip on the classic cut (engine upload consumed as it lands, far partition before the
+    input, outputs drained per channel group): bit for bit what device-buffer launches of the same cut give,
+    over more buffers than the history holds, alone and mixed with device-buffer launches on the SAME plan;
+    the steady state also against the oracle's float64 direct form."""
+    import torch
+    B = 512
+    ir_h = orc.conv_accel_ir(L, T)
+    ir = dev(ir_h)
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="classic")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    h_in = torch.empty(T * B).pin_memory()
+    h_out = torch.empty(T * B).pin_memory()
+    hist = np.zeros(T * L, np.float32)
+    worst = peak = 0.0
+    for i in range(n):
+        x = orc.noise(T * B, seed=90 + i)
+        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+        h_in.copy_(torch.from_numpy(x))
+        h_out.fill_(float("nan"))
+        if i % 5 == 3:                                   # a device-buffer launch in the middle of the stream
+            yb = host(b.process(dev(x), mode=gab.CONV_STREAMING))
+        else:
+            yb = b.round_trip(h_in, h_out).numpy().copy()     # complete when the call returns: no synchronize here
+        assert np.array_equal(bits(ya), bits(yb)), "buffer %d" % i
+        if T <= 64:
+            ref = orc.conv_accel_stream(x, ir_h, hist, L, B, T, f64=True)
+            worst, peak = max(worst, float(np.abs(yb - ref).max())), max(peak, float(np.abs(ref).max()))
+    if T <= 64:
+        assert worst / peak <= 1e-5
+    # the staging buffer is re-armed after every buffer: the same input twice in a row is two buffers, not one
+    x = orc.noise(T * B, seed=7)
+    h_in.copy_(torch.from_numpy(x))
+    for _ in range(2):
+        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+        assert np.array_equal(bits(ya), bits(b.round_trip(h_in, h_out).numpy()))
+    a.close()
+    b.close()
+
+
+def test_conv_accel_round_trip_input_that_holds_the_sentinel(gab, orc):
+    """A buffer that really contains the staging sentinel (a NaN no audio carries) is released by the upload's
+    completion instead of by the words changing: slower, same bits as the device-buffer launch (NaNs and all)."""
+    import torch
+    T, B, L = 16, 512, 4096
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="classic")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    x = orc.noise(T * B, seed=3)
+    xs = x.view(np.uint32).copy()
+    xs[B - 1] = 0xffa5c3e1                               # one thread's word
+    xs[2 * B - 1] = 0xffa5c3e1                           # the word the coarse poll watches
+    xs[5 * B + 17] = 0xffa5c3e1
+    x = xs.view(np.float32)
+    h_in = torch.from_numpy(x.copy()).pin_memory()
+    h_out = torch.empty(T * B).pin_memory()
+    for i in range(3):
+        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+        yb = b.round_trip(h_in, h_out).numpy()
+        # the channel pairs that saw the NaN are NaN in both (which NaN depends on operand order, which two
+        # compilations of the same arithmetic need not share); every other channel is the same bits
+        nan = np.isnan(ya)
+        assert np.array_equal(nan, np.isnan(yb)), "buffer %d" % i
+        assert nan.reshape(B, T)[:, [0, 1, 4, 5]].all() and not nan.reshape(B, T)[:, [2, 3, 6, 7, 15]].any()
+        assert np.array_equal(bits(ya)[~nan], bits(yb)[~nan]), "buffer %d" % i
+    a.close()
+    b.close()
+
+
+def test_conv_accel_round_trip_other_plans_and_arguments(gab, orc):
+    """Plans the overlapped form does not cover (split cut, other buffer sizes) move the buffers by the kernel
+    itself and still return a complete output; the output must be pinned."""
+    import torch
+    for T, B, L, scheme in ((64, 512, 4096, "split"), (6, 256, 700, None), (6, 512, 300, None)):
+        ir = dev(orc.conv_accel_ir(L, T))
+        a, b = gab.ConvPlan(T, B, L, scheme=scheme), gab.ConvPlan(T, B, L, scheme=scheme)
+        a.set_ir(ir)
+        b.set_ir(ir)
+        h_out = torch.empty(T * B).pin_memory()
+        for i in range(3):
+            x = orc.noise(T * B, seed=60 + i)
+            ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+            yb = b.round_trip(torch.from_numpy(x).pin_memory(), h_out).numpy()
+            assert np.array_equal(bits(ya), bits(yb))
+        with pytest.raises(TypeError):
+            b.round_trip(torch.from_numpy(x).pin_memory(), torch.empty(T * B))       # pageable output
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
                                       (4, 512, 1100, 37), (2048, 512, 4096, 3), (12, 512, 4096, 1), (36, 512, 3000, 2),
                                       (8192, 512, 4096, 2),      # C5's channel count: 2048 workgroups, eight rounds of the device

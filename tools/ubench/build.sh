@@ -7,4 +7,7 @@ H=/opt/rocm/bin/hipcc
 $H -O2 --offload-arch=gfx950 tools/ubench/library_baseline.cpp -o tools/ubench/bin/library_baseline -lhipfft
 $H -O3 --offload-arch=gfx950 -ffp-contract=off -I gpuaudiobench_amd/csrc -I include tools/ubench/mfma_dft.hip -o tools/ubench/bin/mfma_dft
 $H -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o tools/ubench/bin/valu_rate
+
+$H -O3 --offload-arch=gfx950 tools/ubench/link_duplex.hip -o tools/ubench/bin/link_duplex
+$H -O3 --offload-arch=gfx950 tools/ubench/link_modes.hip -o tools/ubench/bin/link_modes
 ls -la tools/ubench/bin
