@@ -606,13 +606,24 @@ struct ConvRoundTrip {
     unsigned* stage;                  // [T*B] fine-grained device memory
     float* park;                      // [B*T] device memory
     float* h_out;                     // [B*T] pinned host memory
-    unsigned* counters;               // device: [g] arrivals of group g, [groups] groups drained
+    unsigned* counters;               // device: [32 g + {0,1,2}] arrivals / claims / announced epoch of group g, [32 groups] shares drained
     unsigned* done;                   // pinned host: the epoch, once h_out is complete
     const unsigned* landed;           // pinned host: the epoch, once the host has seen the upload complete
     unsigned* error;                  // pinned host: nonzero if a wait ran out
     unsigned epoch;
     int pairs_per_group, groups;
 };
+
+#ifdef GAB_ABLATE
+// diagnostic builds: s_memrealtime (100 MHz) per channel group — [g][0] first workgroup enters, [1] last workgroup has
+// its rows, [2] last workgroup parked (= the drain starts), [3] drain done; [64][0] the completion word is written
+__device__ unsigned long long g_rt_stamps[65 * 4];
+#define GAB_RT_STAMP_MIN(g, i) do { if (threadIdx.x == 0) atomicMin(&g_rt_stamps[(g) * 4 + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define GAB_RT_STAMP_MAX(g, i) do { if (threadIdx.x == 0) atomicMax(&g_rt_stamps[(g) * 4 + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define GAB_RT_STAMP_MIN(g, i) do {} while (0)
+#define GAB_RT_STAMP_MAX(g, i) do {} while (0)
+#endif
 
 __device__ __forceinline__ unsigned rt_peek(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -628,6 +639,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     const int tid = threadIdx.x;
     const int q = blockIdx.x;                       // pairs in dispatch order: the copy lands them in that order too
     const int ta = 2 * q;
+    const int g = q / rt.pairs_per_group;
+    GAB_RT_STAMP_MIN(g, 0);
     cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
     using FA = fft::BlockFFT<kNA, 4, false>;
     using FAi = fft::BlockFFT<kNA, 4, true>;
@@ -654,6 +667,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
         FBi::template run<typename FB::Twiddles, 2>(zb, lds0, lds1, twb, tid);      // only [14], [15]
     }
     const cf far0 = zb[14], far1 = zb[15];
+
+    // everything else the near partition needs is fetched before the wait
+    float4 ca[4];
+    load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
+    typename FA::Twiddles twa;
+    {
+        typename FA::Bases twa_base;
+        FA::load_twiddles(twa_base, tw, tid);
+        FA::expand_twiddles(twa_base, twa);
+    }
 
     // ---- the pair's two rows: wait until they have landed
     const unsigned* const row = rt.stage + (size_t)ta * kB;                         // 2 x 512 words, contiguous
@@ -689,6 +712,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
             __builtin_amdgcn_s_sleep(10);
         }
     }
+    GAB_RT_STAMP_MAX(g, 1);
     if (gave_up) __hip_atomic_store(rt.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // the words are taken: the sentinel goes back for the next buffer (complete before this launch ends)
     __hip_atomic_store(const_cast<unsigned*>(row) + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -702,14 +726,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     za[1] = prev1;
     za[2] = mk(__uint_as_float(w[0]), __uint_as_float(w[2]));
     za[3] = mk(__uint_as_float(w[1]), __uint_as_float(w[3]));
-    float4 ca[4];
-    load_spectra<kNA, 4>(ca, pmA + (size_t)q * kBinsA, tid);
-    typename FA::Twiddles twa;
-    {
-        typename FA::Bases twa_base;
-        FA::load_twiddles(twa_base, tw, tid);
-        FA::expand_twiddles(twa_base, twa);
-    }
     hp[head * kB + tid] = za[2];                     // the new block replaces the oldest
     hp[head * kB + kThreads + tid] = za[3];
     __syncthreads();                                 // the far partition's last LDS readers are done
@@ -735,56 +751,68 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its own stores
     __syncthreads();
-    const int g = q / rt.pairs_per_group;
+    GAB_RT_STAMP_MAX(g, 2);
+    // ---- the group's slab goes to the pinned output in whole rows of the group's width, shared out among the group's
+    // own workgroups: a slab of `members` pairs is members x 256 float4, one SHARE = 256 consecutive float4 = one per
+    // thread.  Words per group (a 128-byte line each): [0] arrivals (runs on from launch to launch), [1] shares claimed
+    // (zeroed by the last arriver before it announces), [2] the epoch once every member is parked.  A workgroup that
+    // arrives early waits for [2] — bounded, and if it gives up it simply leaves: shares are claimed, not owned, and the
+    // LAST arriver (who never waits) keeps claiming until none is left.  Nobody waits for a workgroup that has not started.
     const int first = g * rt.pairs_per_group;
     const int members = min(rt.pairs_per_group, (int)gridDim.x - first);
+    unsigned* const gw = rt.counters + 32 * g;
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&rt.counters[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_word = (old + 1u == rt.epoch * (unsigned)members) ? 1 : 0;       // counters run on from launch to launch (mod 2^32)
-        if (s_word) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate completes asynchronously
+        const unsigned old = __hip_atomic_fetch_add(&gw[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int role = 1;                                            // 0 gave up, 1 helper, 2 last arriver
+        if (old + 1u == rt.epoch * (unsigned)members) {
+            role = 2;
+            __hip_atomic_store(&gw[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the claim counter is at zero before anyone is told
+            __hip_atomic_store(&gw[2], rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int tries = 0;
+            while (__hip_atomic_load(&gw[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != rt.epoch) {
+                if (++tries > (1 << 10)) { role = 0; break; }   // a fraction of a millisecond: the last arriver drains what is left
+                __builtin_amdgcn_s_sleep(3);
+            }
         }
+        s_word = role;
     }
     __syncthreads();
-    if (s_word == 0) return;
-
-    // ---- the group is complete: its slab, rows of `members` pairs, goes to the pinned output
-    {
-        const int row_f4 = members / 2;                          // float4 per row (members is even: T % 4 == 0)
-        const auto srd = __builtin_amdgcn_make_buffer_rsrc(rt.park, 0, (int)((size_t)T * kB * 4), 0x00020000);
-        const int total = kB * row_f4;                           // float4 of the slab
-        const int col0 = 2 * first;
-        for (int base = 0; base < total; base += 8 * kThreads) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * kThreads + tid;
-                const int sidx = i / row_f4, c = i - sidx * row_f4;
-                const unsigned off = i < total ? 4u * (unsigned)(T * sidx + col0 + 4 * c) : 0xfffffff0u;   // out of range: dropped
-                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, off, 0, 16);                   // sc1
-                v[u] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * kThreads + tid;
-                const int sidx = i / row_f4, c = i - sidx * row_f4;
-                if (i < total) {                                  // system-scope write-through: nothing of it stays behind in a cache
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v val = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    float* const dst = rt.h_out + (size_t)T * sidx + col0 + 4 * c;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
-                }
-            }
-        }
+    const int role = s_word;
+    if (role == 0) return;
+    const int row_f4 = members / 2;                              // float4 per row (members is even: T % 4 == 0)
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc(rt.park, 0, (int)((size_t)T * kB * 4), 0x00020000);
+    const int col0 = 2 * first;
+    unsigned drained = 0;
+    for (;;) {
+        __syncthreads();                                         // s_word's readers of the previous round are done
+        if (tid == 0) s_word = (int)__hip_atomic_fetch_add(&gw[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int share = s_word;
+        if (share >= members) break;
+        const int i = share * kThreads + tid;
+        const int sidx = i / row_f4, c = i - sidx * row_f4;
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, 4u * (unsigned)(T * sidx + col0 + 4 * c), 0, 16);   // sc1
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v val = {__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3])};
+        float* const dst = rt.h_out + (size_t)T * sidx + col0 + 4 * c;
+        // system-scope write-through: nothing of it stays behind in a cache
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
+        ++drained;
+        if (role != 2) break;                                    // helpers take one share; the last arriver takes what is left
     }
-    // every wave waits for its own rows to be accepted by the link's ordered queue, THEN the group counts as drained;
-    // the launch's last drain therefore issues the completion word behind every row of every group
+    // every wave waits for its own rows to be accepted by the link's ordered queue, THEN its shares count as drained; the
+    // workgroup whose count completes the launch therefore issues the completion word behind every row of every group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&rt.counters[rt.groups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == rt.epoch * (unsigned)rt.groups) __hip_atomic_store(rt.done, rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    GAB_RT_STAMP_MAX(g, 3);
+    if (tid == 0 && drained) {
+        const unsigned old = __hip_atomic_fetch_add(&rt.counters[32 * rt.groups], drained, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + drained == rt.epoch * (unsigned)gridDim.x) {
+            __hip_atomic_store(rt.done, rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            GAB_RT_STAMP_MAX(64, 0);
+        }
     }
 }
 
@@ -1745,8 +1773,8 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     ppg += ppg & 1;                                   // whole float4 columns per row
     p->rt_pairs_per_group = ppg;
     p->rt_groups = (p->pairs + ppg - 1) / ppg;
-    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * (p->rt_groups + 1)));
-    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * (p->rt_groups + 1)));
+    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 1)));      // a 128-byte line per group
+    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 1)));
     GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
     for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
     GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
@@ -1863,6 +1891,16 @@ int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* histor
 }
 
 #ifdef GAB_ABLATE
+// diagnostic builds only: arm (mins to ~0ull, maxes to 0) / read the round-trip kernel's per-group stamps
+int gab_debug_rt_stamps(unsigned long long* h_out, int arm) {
+    (void)hipDeviceSynchronize();
+    if (arm) {
+        unsigned long long init[65 * 4];
+        for (int i = 0; i < 65 * 4; ++i) init[i] = (i % 4 == 0 && i < 64 * 4) ? ~0ull : 0ull;
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(gab::g_rt_stamps), init, sizeof init);
+    }
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_rt_stamps), sizeof(unsigned long long) * 65 * 4);
+}
 // diagnostic builds only: copies the phase stamps of the last stamped split launch
 int gab_debug_split_stamps(unsigned long long* h_out, int n) {
     (void)hipDeviceSynchronize();
