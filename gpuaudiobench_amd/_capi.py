@@ -82,6 +82,7 @@ PROTOTYPES = {
     "gab_iir": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_iir_sequential": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_conv1d": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "gab_conv1d_shard": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "gab_rndmem": (_I, [_P, _P, _P, _I, _I, _P]),
     "gab_modal": (_I, [_P, _P, _I, _I, _I, _P]),
     "gab_modal_bank_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -128,6 +129,9 @@ PROTOTYPES = {
     "gab_bench_name": (C.c_char_p, [_I]),
     "gab_bench_create": (_I, [C.POINTER(_P), C.c_char_p, C.POINTER(BenchConfig)]),
     "gab_bench_destroy": (_I, [_P]),
+    "gab_bench_set_shard": (_I, [_P, _Z, _Z]),
+    "gab_bench_result_count": (_I, [_P]),
+    "gab_bench_result_array": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z)]),
     "gab_bench_setup": (_I, [_P]),
     "gab_bench_run": (_I, [_P, _I, _I, C.POINTER(BenchResult)]),
     "gab_bench_validate": (_I, [_P, C.POINTER(BenchValidation)]),

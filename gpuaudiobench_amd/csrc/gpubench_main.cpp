@@ -40,8 +40,10 @@ void printHelp() {
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
     printf("  --convBatch [n]     Conv1D_accel: an iteration is ONE launch over n HBM-resident buffers (throughput mode,\n");
     printf("                      no per-iteration copies); default: one buffer per iteration with its copies\n");
-    printf("  --gpus [n]          Run on n devices, one host thread each: Conv1D_accel as contiguous channel shards of\n");
-    printf("                      --nTracks with the impulse-response bank broadcast once over RCCL; others as replicas\n");
+    printf("  --gpus [n]          Run on n devices, one host thread each: gain, GainStats, IIRFilter, FFT1D, RndMemRead, Conv1D\n");
+    printf("                      and Conv1D_accel as contiguous channel shards of --nTracks (Conv1D_accel's impulse-response\n");
+    printf("                      bank broadcast once over RCCL; Conv1D with its halo rows; RndMemRead with the pool on every\n");
+    printf("                      device); DWG, modal, FDTD3D, datacopy, NoOp as replicas\n");
     printf("  --print-shards      Print the channel shards --gpus / --nTracks give and exit (no device is touched)\n");
     printf("  --validate-only     Set up, validate against the CPU golden, exit 0/1; no timed loop\n");
     printf("  --cpu-threads [n]   Threads for the timed CPU golden (default: all hardware threads; 0 = skip it)\n");
@@ -194,7 +196,7 @@ int runOnSeveralDevices(const std::string& name) {
         cfg.validate_only = g_validate_only;
         const gab::MultiGpuReport rep = gab::runOnDevices(cfg);
         printf("%s on %d device(s): %s; %zu tracks in all\n", name.c_str(), rep.gpus,
-               rep.sharded ? "contiguous channel shards, no per-buffer collective" : "replicas only", rep.total_tracks);
+               rep.partition.c_str(), rep.total_tracks);
         if (rep.ir_broadcast_ms >= 0.0)
             printf("Impulse-response bank: %zu bytes broadcast with RCCL in %.3f ms (%.1f GB/s)\n", rep.ir_bank_bytes,
                    rep.ir_broadcast_ms, rep.ir_bank_bytes / (rep.ir_broadcast_ms * 1e-3) / 1e9);
@@ -310,9 +312,20 @@ int main(int argc, char** argv) {
     if (print_shards) {
         const int world = g_gpus > 0 ? g_gpus : 1;
         if ((size_t)world > (size_t)NTRACKS) { printf("Error: more GPUs than tracks\n"); return 1; }
+        if (!gab::benchmarkShards(which)) {
+            printf("%s: replicas only (its tracks reduce into shared outputs): %d x %d tracks\n", which.c_str(), world, NTRACKS);
+            return 0;
+        }
+        const int L = IR_LENGTH > 0 ? IR_LENGTH : Conv1DBenchmark::DEFAULT_IR_LEN;
         for (int r = 0; r < world; ++r) {
             const gab::ShardRange s = gab::shardRange(r, world, (size_t)NTRACKS);
-            printf("shard %d: tracks [%zu, %zu) = %zu\n", r, s.lo, s.hi, s.count());
+            if (which == "Conv1D") {          // its golden convolves the flat input: the preceding tracks' rows come along
+                const size_t halo = std::min(s.lo, ((size_t)L - 1 + (size_t)BUFSIZE - 1) / (size_t)BUFSIZE);
+                printf("shard %d: tracks [%zu, %zu) = %zu, input rows from track %zu (halo %zu)\n", r, s.lo, s.hi, s.count(),
+                       s.lo - halo, halo);
+            } else {
+                printf("shard %d: tracks [%zu, %zu) = %zu\n", r, s.lo, s.hi, s.count());
+            }
         }
         return 0;
     }

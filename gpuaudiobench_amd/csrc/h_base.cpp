@@ -60,7 +60,25 @@ void GPUABenchmark::transferToHost() {
 
 void GPUABenchmark::generateTestData(unsigned int seed) {
     if (!buffers.h_input) throw std::runtime_error("generateTestData called before host input buffer allocation");
-    BenchmarkUtils::generateRandomAudioData(buffers.h_input, buffers.element_count, seed);
+    if (isShard())     // the rows of this shard's tracks out of the one flat stream over all tracks
+        BenchmarkUtils::generateRandomAudioDataFrom(buffers.h_input, buffers.element_count, seed,
+                                                    static_cast<unsigned long long>(shard_first_) * buffer_size_);
+    else
+        BenchmarkUtils::generateRandomAudioData(buffers.h_input, buffers.element_count, seed);
+}
+
+void GPUABenchmark::setShard(size_t first_track, size_t total_tracks) {
+    if (total_tracks == 0 || first_track + track_count_ > total_tracks)
+        throw std::invalid_argument("setShard: tracks [first, first + count) must lie inside the job's total_tracks");
+    if (!shardable())
+        throw std::invalid_argument("setShard: " + benchmark_name_ + " has no independent tracks to shard (replicas only)");
+    if (buffers.h_input) throw std::invalid_argument("setShard must be called before setupBenchmark()");
+    shard_first_ = first_track;
+    shard_total_ = total_tracks;
+}
+
+std::vector<GPUABenchmark::ResultArray> GPUABenchmark::resultArrays() const {
+    return {{"output", buffers.h_output, buffers.element_count, 0, buffer_size_}};
 }
 
 GPUABenchmark::BenchmarkResult GPUABenchmark::runKernelBenchmark(int iterations, int warmupIterations) {

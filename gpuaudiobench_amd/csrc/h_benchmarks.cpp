@@ -10,6 +10,8 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 
 #include "gab/benchmarks.hpp"
 #include "h_golden.hpp"
@@ -194,6 +196,10 @@ void GainStatsBenchmark::validate(ValidationData& v) {
     }
 }
 
+std::vector<GPUABenchmark::ResultArray> GainStatsBenchmark::resultArrays() const {
+    return {{"output", hostOutput(), getTotalElements(), 0, getBufferSize()}, {"stats", h_stats, stats_count, 0, NSTATS}};
+}
+
 size_t GainStatsBenchmark::algorithmicBytes() const {
     return 2 * getTotalElements() * sizeof(float) + stats_size_bytes;
 }
@@ -292,10 +298,15 @@ void FFTBenchmark::setupBenchmark() {
     d_output_fft = allocateDeviceBuffer<float2>(output_fft_size, benchmark_name_ + " device output FFT buffer");
     std::memset(h_output_fft, 0, output_fft_bytes);
 
+    // The reference draws from an unseeded rand() (cuda/bench_fft.cu:37), one benchmark per process: the stream
+    // srand(1) starts.  Drawn from a private generator, so that neither other rand() users nor other ranks' threads
+    // move it, and a shard can enter it at its first track.
     const size_t per_track = std::min(getBufferSize(), static_cast<size_t>(FFT_SIZE));
+    BenchmarkUtils::GlibcRand rng(1);
+    rng.discard(static_cast<unsigned long long>(shardFirstTrack()) * per_track);
     for (size_t t = 0; t < getTrackCount(); ++t) {
         for (size_t i = 0; i < per_track; ++i)
-            h_input_fft[t * FFT_SIZE + i] = ((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f;
+            h_input_fft[t * FFT_SIZE + i] = ((float)rng.next() / (float)RAND_MAX) * 2.0f - 1.0f;
         for (size_t i = per_track; i < FFT_SIZE; ++i) h_input_fft[t * FFT_SIZE + i] = 0.0f;
     }
     cpu_reference_real = allocateHostBuffer<float>(output_fft_size, "fft cpu reference real");
@@ -358,6 +369,10 @@ void FFTBenchmark::validate(ValidationData& v) {
 }
 
 size_t FFTBenchmark::algorithmicBytes() const { return input_fft_bytes + output_fft_bytes; }
+
+std::vector<GPUABenchmark::ResultArray> FFTBenchmark::resultArrays() const {
+    return {{"spectrum", reinterpret_cast<const float*>(h_output_fft), 2 * output_fft_size, 0, 2 * (FFT_SIZE / 2 + 1)}};
+}
 
 // ===========================================================================
 // IIRFilter
@@ -443,6 +458,10 @@ void IIRBenchmark::validate(ValidationData& v) {
     }
 }
 
+std::vector<GPUABenchmark::ResultArray> IIRBenchmark::resultArrays() const {
+    return {{"output", hostOutput(), getTotalElements(), 0, getBufferSize()}, {"state", h_state, state_count, 0, STATES_PER_TRACK}};
+}
+
 size_t IIRBenchmark::algorithmicBytes() const {
     return 2 * getTotalElements() * sizeof(float) + 2 * state_size_bytes + sizeof(IIRCoefficients);
 }
@@ -458,25 +477,49 @@ Conv1DBenchmark::Conv1DBenchmark(int ir_length, size_t buffer_size, size_t track
 }
 
 Conv1DBenchmark::~Conv1DBenchmark() {
-    freeHostBuffers({h_ir_buf, cpu_reference});
-    freeDeviceBuffers({d_ir_buf});
+    freeHostBuffers({h_ir_buf, cpu_reference, h_halo_in_});
+    freeDeviceBuffers({d_ir_buf, d_halo_in_});
 }
 
 void Conv1DBenchmark::setupBenchmark() {
     allocateBuffers(getTotalElements());
     h_ir_buf = allocateHostBuffer<float>(ir_buffer_size, benchmark_name_ + " host IR buffer");
     d_ir_buf = allocateDeviceBuffer<float>(ir_buffer_size, benchmark_name_ + " device IR buffer");
-    BenchmarkUtils::generateConv1DImpulseResponses(h_ir_buf, ir_length_, 0, getTrackCount(), getTrackCount());
+    // the bank's formula takes the GLOBAL track index and count (cuda/bench_conv1d.cu:166-176)
+    BenchmarkUtils::generateConv1DImpulseResponses(h_ir_buf, ir_length_, shardFirstTrack(), getTrackCount(), jobTracks());
     HIP_CHECK(hipMemcpy(d_ir_buf, h_ir_buf, ir_buffer_bytes, hipMemcpyHostToDevice));
     generateTestData(42);
     cpu_reference = allocateHostBuffer<float>(getTotalElements(), "conv1d cpu reference");
-    gab::golden::conv1d(getHostInput(), h_ir_buf, cpu_reference, ir_length_,
-                        static_cast<int>(getBufferSize()), static_cast<int>(getTrackCount()));
+    if (isShard()) {
+        // The golden convolves the FLAT input: a track's history is the end of the track before it
+        // (cuda/bench_conv1d.cu:188-208), so a shard needs the last L-1 samples in front of its first track: the
+        // ceil((L-1)/B) preceding tracks' rows (fewer at the job's start), provided by the host with the shard's own
+        // rows — no exchange between devices.
+        const size_t B = getBufferSize();
+        halo_tracks_ = std::min(shardFirstTrack(), (static_cast<size_t>(ir_length_) - 1 + B - 1) / B);
+        const size_t n = (halo_tracks_ + getTrackCount()) * B;
+        h_halo_in_ = allocateHostBuffer<float>(n, "conv1d host input with halo tracks");
+        d_halo_in_ = allocateDeviceBuffer<float>(n, "conv1d device input with halo tracks");
+        BenchmarkUtils::generateRandomAudioDataFrom(h_halo_in_, n, 42,
+                                                    static_cast<unsigned long long>(shardFirstTrack() - halo_tracks_) * B);
+        gab::golden::conv1d_shard_rows(h_halo_in_, h_ir_buf, cpu_reference, ir_length_, static_cast<int>(B), 0,
+                                       static_cast<int>(getTrackCount()), static_cast<int>(getTrackCount()),
+                                       static_cast<int>(halo_tracks_));
+    } else {
+        gab::golden::conv1d(getHostInput(), h_ir_buf, cpu_reference, ir_length_,
+                            static_cast<int>(getBufferSize()), static_cast<int>(getTrackCount()));
+    }
     say("Conv1D benchmark setup complete (IR length = %d, taps staged through LDS)\n", ir_length_);
 }
 
 bool Conv1DBenchmark::cpuGoldenSlice(size_t first, size_t count) {
     if (!cpu_reference) return false;
+    if (isShard()) {
+        gab::golden::conv1d_shard_rows(h_halo_in_, h_ir_buf, cpu_reference, ir_length_, static_cast<int>(getBufferSize()),
+                                       static_cast<int>(first), static_cast<int>(first + count),
+                                       static_cast<int>(getTrackCount()), static_cast<int>(halo_tracks_));
+        return true;
+    }
     gab::golden::conv1d_rows(getHostInput(), h_ir_buf, cpu_reference, ir_length_, static_cast<int>(getBufferSize()),
                              static_cast<int>(first), static_cast<int>(first + count), static_cast<int>(getTrackCount()));
     return true;
@@ -485,6 +528,17 @@ bool Conv1DBenchmark::cpuGoldenSlice(size_t first, size_t count) {
 void Conv1DBenchmark::runKernel() { performBenchmarkIteration(); }
 
 void Conv1DBenchmark::performBenchmarkIteration() {
+    if (isShard()) {                         // the halo rows travel with the shard's own
+        HIP_CHECK(hipMemcpyAsync(d_halo_in_, h_halo_in_, (halo_tracks_ + getTrackCount()) * getBufferSize() * sizeof(float),
+                                 hipMemcpyHostToDevice, stream_));
+        ScopedGpuTimer g(stream_);
+        checkGab(gab_conv1d_shard(d_halo_in_, getDeviceOutput(), d_ir_buf, ir_length_, static_cast<int>(getTrackCount()),
+                                  static_cast<int>(getBufferSize()), static_cast<int>(halo_tracks_), stream_),
+                 "gab_conv1d_shard");
+        recordGpuDuration(g.finish());
+        transferToHost();
+        return;
+    }
     transferToDevice();
     ScopedGpuTimer g(stream_);
     checkGab(gab_conv1d(getDeviceInput(), getDeviceOutput(), d_ir_buf, ir_length_,
@@ -505,7 +559,7 @@ void Conv1DBenchmark::validate(ValidationData& v) {
 }
 
 size_t Conv1DBenchmark::algorithmicBytes() const {
-    return 2 * getTotalElements() * sizeof(float) + ir_buffer_bytes;
+    return 2 * getTotalElements() * sizeof(float) + ir_buffer_bytes + halo_tracks_ * getBufferSize() * sizeof(float);
 }
 
 // ===========================================================================
@@ -535,6 +589,7 @@ Conv1DAccelBenchmark::~Conv1DAccelBenchmark() {
 
 void Conv1DAccelBenchmark::setupBenchmark() {
     say("Setting up Conv1D accelerated benchmark...\n");
+    if (isShard()) { track_offset_ = shardFirstTrack(); total_tracks_ = jobTracks(); }      // setShard() = the constructor's pair
     allocateBuffers(getTotalElements());
     // a shard takes its rows of the one flat noise stream over ALL tracks (cuda/bench_utils.cu:238-245)
     BenchmarkUtils::generateRandomAudioDataFrom(getHostInput(), getTotalElements(), 42,
@@ -570,6 +625,10 @@ void Conv1DAccelBenchmark::setupBenchmark() {
         say("Conv1D accelerated: %d resident buffers per iteration, one launch\n", batch_);
     }
     say("Conv1D accelerated benchmark setup complete.\n");
+}
+
+std::vector<GPUABenchmark::ResultArray> Conv1DAccelBenchmark::resultArrays() const {
+    return {{"output", hostOutput(), getTotalElements(), 1, getBufferSize()}};          // out[T*s + t]
 }
 
 bool Conv1DAccelBenchmark::cpuGoldenSlice(size_t first, size_t count) {
@@ -1014,9 +1073,25 @@ void RndMemBenchmark::setupBenchmark() {
     playheads_end = allocateHostBuffer<float>(T, "rndmem playheads end");
     std::memset(h_output_buffer, 0, output_buffer_bytes);
 
-    srand(42);
-    for (int i = 0; i < SAMPLE_MEM_NUM_ELEMS; ++i)
-        h_sample_memory[i] = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+    // srand(42) + 2^27 draws (cuda/bench_rndmem.cu:140-149), from a private generator (other ranks' threads cannot
+    // interleave with it); ranks of one process — every shard needs the WHOLE pool — generate it once and copy
+    {
+        static std::mutex pool_mu;
+        static std::weak_ptr<std::vector<float>> pool_cache;
+        std::shared_ptr<std::vector<float>> pool;
+        {
+            std::lock_guard<std::mutex> lock(pool_mu);
+            pool = pool_cache.lock();
+            if (!pool) {
+                pool = std::make_shared<std::vector<float>>(static_cast<size_t>(SAMPLE_MEM_NUM_ELEMS));
+                BenchmarkUtils::GlibcRand rng(42);
+                for (int i = 0; i < SAMPLE_MEM_NUM_ELEMS; ++i)
+                    (*pool)[i] = static_cast<float>(rng.next()) / static_cast<float>(RAND_MAX);
+                pool_cache = pool;
+            }
+        }
+        std::memcpy(h_sample_memory, pool->data(), sample_memory_bytes);
+    }
     say("Transferring 512MB sample memory to device...\n");
     HIP_CHECK(hipMemcpy(d_sample_memory, h_sample_memory, sample_memory_bytes, hipMemcpyHostToDevice));
     say("Sample memory transfer complete.\n");
@@ -1036,11 +1111,12 @@ bool RndMemBenchmark::cpuGoldenWhole() {
 }
 
 void RndMemBenchmark::initializePlayheads() {
-    srand(42);
+    BenchmarkUtils::GlibcRand rng(42);                   // the reference re-seeds: srand(42) (cuda/bench_rndmem.cu:152)
+    rng.discard(2ull * shardFirstTrack());               // two draws per track: a shard starts at its first track's
     for (size_t i = 0; i < getTrackCount(); ++i) {
         // start/end are kept as floats, as in the reference (24-bit mantissa rounding included)
-        playheads_start[i] = static_cast<float>(rand() % sample_buffer_end_);
-        int loop_len = min_loop_length_ + (rand() % (max_loop_length_ - min_loop_length_));
+        playheads_start[i] = static_cast<float>(rng.next() % sample_buffer_end_);
+        int loop_len = min_loop_length_ + (rng.next() % (max_loop_length_ - min_loop_length_));
         playheads_end[i] = playheads_start[i] + loop_len;
         if (playheads_end[i] >= sample_buffer_end_) playheads_end[i] = sample_buffer_end_ - 1;
         h_playheads[i] = static_cast<int>(playheads_start[i]);
@@ -1081,6 +1157,10 @@ void RndMemBenchmark::validate(ValidationData& v) {
     v.messages.push_back(v.status == ValidationStatus::SUCCESS
                              ? "RndMem validation passed (memory access patterns verified)"
                              : "RndMem validation failed");
+}
+
+std::vector<GPUABenchmark::ResultArray> RndMemBenchmark::resultArrays() const {
+    return {{"output", h_output_buffer, getTotalElements(), 1, getBufferSize()}};       // out[T*i + t]
 }
 
 // ===========================================================================
@@ -1131,6 +1211,29 @@ std::unique_ptr<GPUABenchmark> createBenchmark(const std::string& name) {
     for (const Entry& e : kRegistry)
         if (name == e.name) return e.make();
     return nullptr;
+}
+
+// The benchmarks with independent tracks, built for `tracks` of them (a channel shard; every other parameter from the
+// process globals as createBenchmark does).  nullptr for the rest: they reduce into shared outputs — replicas only.
+std::unique_ptr<GPUABenchmark> createBenchmarkShard(const std::string& name, size_t tracks) {
+    if (name == "gain") return mk<GainBenchmark>(static_cast<size_t>(BUFSIZE), tracks);
+    if (name == "GainStats") return mk<GainStatsBenchmark>(static_cast<size_t>(BUFSIZE), tracks);
+    if (name == "FFT1D") return mk<FFTBenchmark>(static_cast<size_t>(BUFSIZE), tracks);
+    if (name == "IIRFilter") return mk<IIRBenchmark>(static_cast<size_t>(BUFSIZE), tracks);
+    if (name == "RndMemRead") return mk<RndMemBenchmark>(static_cast<size_t>(BUFSIZE), tracks);
+    if (name == "Conv1D")
+        return mk<Conv1DBenchmark>(IR_LENGTH > 0 ? IR_LENGTH : Conv1DBenchmark::DEFAULT_IR_LEN, static_cast<size_t>(BUFSIZE), tracks);
+    if (name == "Conv1D_accel")
+        return mk<Conv1DAccelBenchmark>(IR_LENGTH > 0 ? IR_LENGTH : Conv1DAccelBenchmark::DEFAULT_IR_LEN,
+                                        static_cast<size_t>(BUFSIZE), tracks,
+                                        CONV_STREAMING ? Conv1DAccelBenchmark::Mode::STREAMING : Conv1DAccelBenchmark::Mode::STATELESS);
+    return nullptr;
+}
+
+bool benchmarkShards(const std::string& name) {
+    for (const char* n : {"gain", "GainStats", "FFT1D", "IIRFilter", "RndMemRead", "Conv1D", "Conv1D_accel"})
+        if (name == n) return true;
+    return false;
 }
 
 }  // namespace gab

@@ -142,6 +142,33 @@ int gab_bench_destroy(gab_bench* b) {
     return GAB_OK;
 }
 
+int gab_bench_set_shard(gab_bench* b, size_t first_track, size_t total_tracks) {
+    return gab::guarded([&]() -> int {
+        if (!b) return gab::bad_arg("gab_bench_set_shard: null benchmark");
+        if (b->set_up) return gab::bad_arg("gab_bench_set_shard: call it before gab_bench_setup");
+        b->impl->setShard(first_track, total_tracks);
+        return GAB_OK;
+    });
+}
+
+int gab_bench_result_count(gab_bench* b) { return (b && b->set_up) ? static_cast<int>(b->impl->resultArrays().size()) : 0; }
+
+int gab_bench_result_array(gab_bench* b, int index, const char** name, const float** data, size_t* count, int* layout,
+                           size_t* per_track) {
+    return gab::guarded([&]() -> int {
+        if (!b || !b->set_up) return gab::bad_arg("gab_bench_result_array: no benchmark that has been set up");
+        const auto arrays = b->impl->resultArrays();
+        if (index < 0 || index >= static_cast<int>(arrays.size())) return gab::bad_arg("gab_bench_result_array: index out of range");
+        const auto& a = arrays[index];
+        if (name) *name = a.name;
+        if (data) *data = a.data;
+        if (count) *count = a.count;
+        if (layout) *layout = a.layout;
+        if (per_track) *per_track = a.per_track;
+        return GAB_OK;
+    });
+}
+
 int gab_bench_setup(gab_bench* b) {
     return gab::guarded([&]() -> int {
         if (!b) return gab::bad_arg("gab_bench_setup: null benchmark");

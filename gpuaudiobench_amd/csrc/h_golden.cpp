@@ -110,6 +110,23 @@ void conv1d_rows(const float* in, const float* ir, float* out, int L, int B, int
         }
 }
 
+// The same loop for tracks [t_lo, t_hi) of a SHARD of T tracks whose input buffer starts `halo` tracks before its first
+// own track (the flat index runs over the halo rows too; before them lies either nothing — the job's start — or
+// samples no tap of these tracks reaches).  ir and out hold the shard's own tracks only.
+void conv1d_shard_rows(const float* in_with_halo, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T,
+                       int halo) {
+    const long total = static_cast<long>(halo + T) * B;
+    for (int t = t_lo; t < t_hi; ++t)
+        for (int i = 0; i < B; ++i) {
+            float samp = 0.0f;
+            for (int j = 0; j < L; ++j) {
+                long idx = static_cast<long>(halo + t) * B + i - j;
+                if (idx >= 0 && idx < total) samp += ir[static_cast<size_t>(t) * L + j] * in_with_halo[idx];
+            }
+            out[static_cast<size_t>(t) * B + i] = samp;
+        }
+}
+
 void conv1d(const float* in, const float* ir, float* out, int L, int B, int T) {
     std::memset(out, 0, sizeof(float) * static_cast<size_t>(T) * B);
     conv1d_rows(in, ir, out, L, B, 0, T, T);

@@ -29,6 +29,8 @@ void conv1d(const float* in, const float* ir, float* out, int L, int B, int T); 
 void conv_accel(const float* in, const float* ir, float* out, int L, int B, int T);  // bench_conv1d_accel.cu:234-252
 // the same loops for tracks [t_lo, t_hi) only (the CPU baseline cuts the tracks over threads)
 void conv1d_rows(const float* in, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T);
+void conv1d_shard_rows(const float* in_with_halo, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T,
+                       int halo);
 void conv_accel_rows(const float* in, const float* ir, float* out, int L, int B, int t_lo, int t_hi, int T);
 void modal(const float* params, float* out, int n_modes, int B, int out_tracks); // bench_modal.cu:152-179
 // the real bank: metal-swift/MetalSwiftBench/Benchmarks/ModalFilterBankBenchmark.swift:73-101

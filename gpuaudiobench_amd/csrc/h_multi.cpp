@@ -188,7 +188,8 @@ MultiGpuReport runOnDevices(const MultiGpuConfig& cfg) {
 
     MultiGpuReport rep;
     rep.gpus = cfg.gpus;
-    rep.sharded = cfg.benchmark == "Conv1D_accel";
+    rep.sharded = benchmarkShards(cfg.benchmark);
+    const bool bank = cfg.benchmark == "Conv1D_accel";          // the one benchmark with a one-time exchange
     rep.total_tracks = rep.sharded ? static_cast<size_t>(NTRACKS) : static_cast<size_t>(NTRACKS) * cfg.gpus;
     rep.collective = "none";
     rep.ranks.resize(cfg.gpus);
@@ -196,17 +197,30 @@ MultiGpuReport runOnDevices(const MultiGpuConfig& cfg) {
         throw std::invalid_argument("more GPUs than tracks");
 
     const int ir_len = IR_LENGTH > 0 ? IR_LENGTH : Conv1DAccelBenchmark::DEFAULT_IR_LEN;
-    SharedBank bank;
-    if (rep.sharded) {
-        bank = broadcastConvAccelBank(cfg.gpus, ir_len, rep.total_tracks);
-        rep.ir_bank_bytes = bank.bytes;
-        rep.ir_broadcast_ms = bank.broadcast_ms;
+    SharedBank shared;
+    if (bank) {
+        shared = broadcastConvAccelBank(cfg.gpus, ir_len, rep.total_tracks);
+        rep.ir_bank_bytes = shared.bytes;
+        rep.ir_broadcast_ms = shared.broadcast_ms;
         rep.collective = "rccl ncclCommInitAll + ncclBroadcast (once, before the first buffer)";
+    }
+    if (rep.sharded) {
+        if (cfg.benchmark == "Conv1D")
+            rep.partition = "contiguous channel shards + the ceil((L-1)/B) preceding tracks' input rows as a halo from the host, no collective";
+        else if (cfg.benchmark == "RndMemRead")
+            rep.partition = "contiguous channel shards, the 512 MiB pool on every rank (generated once, uploaded by each), no collective";
+        else if (bank)
+            rep.partition = "contiguous channel shards, impulse-response bank broadcast once, no per-buffer collective";
+        else
+            rep.partition = "contiguous channel shards, no collective";
+    } else {
+        rep.partition = "replicas only";
     }
 
     const bool quiet_before = GAB_QUIET;
     if (cfg.gpus > 1) GAB_QUIET = true;           // the ranks' progress chatter would interleave
     Rendezvous meet(cfg.gpus);
+    std::mutex setup_mu;
     auto rank_body = [&](int r) {
         RankReport& out = rep.ranks[r];
         out.device = r;
@@ -216,18 +230,22 @@ MultiGpuReport runOnDevices(const MultiGpuConfig& cfg) {
             std::unique_ptr<GPUABenchmark> b;
             if (rep.sharded) {
                 out.tracks = shardRange(r, cfg.gpus, rep.total_tracks);
-                auto conv = std::make_unique<Conv1DAccelBenchmark>(
-                    ir_len, BUFSIZE, out.tracks.count(),
-                    CONV_STREAMING ? Conv1DAccelBenchmark::Mode::STREAMING : Conv1DAccelBenchmark::Mode::STATELESS,
-                    out.tracks.lo, rep.total_tracks);
-                conv->shareImpulseResponses(bank.d_bank[r] + out.tracks.lo * static_cast<size_t>(ir_len));
-                b = std::move(conv);
+                b = createBenchmarkShard(cfg.benchmark, out.tracks.count());
+                b->setShard(out.tracks.lo, rep.total_tracks);
+                if (bank)
+                    static_cast<Conv1DAccelBenchmark*>(b.get())->shareImpulseResponses(
+                        shared.d_bank[r] + out.tracks.lo * static_cast<size_t>(ir_len));
             } else {
                 out.tracks.lo = 0;
                 out.tracks.hi = static_cast<size_t>(NTRACKS);
                 b = createBenchmark(cfg.benchmark);
             }
-            b->setupBenchmark();
+            {
+                // one rank at a time: the replicas' generators draw from the process-wide rand() (DWG, modal, FDTD3D,
+                // datacopy), whose stream concurrent threads would interleave
+                std::lock_guard<std::mutex> lock(setup_mu);
+                b->setupBenchmark();
+            }
             out.algorithmic_bytes = b->algorithmicBytes();
             meet.arrive();
             arrived = true;
@@ -244,7 +262,7 @@ MultiGpuReport runOnDevices(const MultiGpuConfig& cfg) {
     rank_body(0);
     for (auto& t : pool) t.join();
     GAB_QUIET = quiet_before;
-    if (rep.sharded) bank.release();
+    if (bank) shared.release();
     (void)hipSetDevice(0);
 
     for (const auto& r : rep.ranks) {
@@ -261,7 +279,7 @@ std::string multiGpuJson(const MultiGpuReport& r) {
     char buf[512];
     std::string j = "  \"multi_gpu\": {\n";
     snprintf(buf, sizeof buf, "    \"gpus\": %d,\n    \"partition\": \"%s\",\n    \"total_tracks\": %zu,\n", r.gpus,
-             r.sharded ? "contiguous channel shards, no per-buffer collective" : "replicas only", r.total_tracks);
+             r.partition.c_str(), r.total_tracks);
     j += buf;
     j += "    \"collective\": \"" + r.collective + "\",\n";
     snprintf(buf, sizeof buf, "    \"ir_bank_bytes\": %zu,\n    \"ir_broadcast_ms\": %s,\n", r.ir_bank_bytes,

@@ -372,6 +372,27 @@ void generateRandomAudioDataFrom(float* buffer, size_t samples, unsigned int see
     for (size_t i = 0; i < samples; ++i) buffer[i] = dist(gen);
 }
 
+GlibcRand::GlibcRand(unsigned int seed) : f_(3), b_(0) {
+    int word = static_cast<int>(seed ? seed : 1u);
+    r_[0] = static_cast<unsigned int>(word);
+    for (int i = 1; i < 31; ++i) {                       // word = 16807 * word mod (2^31 - 1), Schrage's split
+        const long hi = word / 127773, lo = word % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = static_cast<int>(w);
+        r_[i] = static_cast<unsigned int>(word);
+    }
+    for (int i = 0; i < 310; ++i) (void)next();
+}
+
+int GlibcRand::next() {
+    r_[f_] += r_[b_];
+    const unsigned int out = r_[f_] >> 1;
+    if (++f_ >= 31) f_ = 0;
+    if (++b_ >= 31) b_ = 0;
+    return static_cast<int>(out);
+}
+
 void generateImpulseResponse(float* buffer, int length, float frequency, WindowType window_type) {
     for (int i = 0; i < length; ++i) {
         float t = static_cast<float>(i) - static_cast<float>(length) / 2.0f;

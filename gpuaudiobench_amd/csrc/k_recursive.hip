@@ -320,13 +320,15 @@ __device__ __forceinline__ float conv1d_tile(const float* __restrict__ in, const
 __global__ __launch_bounds__(kConvTile) void conv1d_direct_kernel(const float* __restrict__ in,
                                                                  float* __restrict__ out,
                                                                  const float* __restrict__ ir,
-                                                                 int L, int T, int B) {
+                                                                 int L, int T, int B, int halo) {
     __shared__ float taps[kTapChunk + 2 * kTapGroup];
     __shared__ float win[kTapGroup + kTapChunk + kConvTile];
     const int t = blockIdx.y;
     const int i0 = blockIdx.x * kConvTile;
-    const long flat0 = (long)t * B + i0;           // flat index of this tile's first output
-    const long total = (long)T * B;
+    // `in` starts `halo` tracks before the first track computed here (a channel shard's input; 0 for a whole job):
+    // the flat index runs over those rows too, `ir` and `out` hold the computed tracks only
+    const long flat0 = (long)(halo + t) * B + i0;  // flat index of this tile's first output
+    const long total = (long)(halo + T) * B;
     const float* h = ir + (size_t)t * L;
     const float acc = flat0 >= L - 1 ? conv1d_tile<false>(in, h, L, flat0, total, taps, win)
                                      : conv1d_tile<true>(in, h, L, flat0, total, taps, win);
@@ -595,16 +597,21 @@ int gab_iir(const float* d_in, float* d_out, const float* coeffs, float* d_state
     });
 }
 
-int gab_conv1d(const float* d_in, float* d_out, const float* d_ir, int ir_len, int tracks,
-               int bufsize, gab_stream_t stream) {
+int gab_conv1d_shard(const float* d_in, float* d_out, const float* d_ir, int ir_len, int tracks,
+                     int bufsize, int halo_tracks, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!d_in || !d_out || !d_ir) return gab::bad_arg("gab_conv1d: null pointer");
-        if (ir_len <= 0 || tracks <= 0 || bufsize <= 0) return gab::bad_arg("gab_conv1d: sizes must be > 0");
+        if (ir_len <= 0 || tracks <= 0 || bufsize <= 0 || halo_tracks < 0) return gab::bad_arg("gab_conv1d: sizes must be > 0");
         dim3 grid((bufsize + gab::kConvTile - 1) / gab::kConvTile, tracks);
         gab::conv1d_direct_kernel<<<grid, gab::kConvTile, 0, gab::as_stream(stream)>>>(
-            d_in, d_out, d_ir, ir_len, tracks, bufsize);
+            d_in, d_out, d_ir, ir_len, tracks, bufsize, halo_tracks);
         return gab::launch_status("conv1d_direct_kernel");
     });
+}
+
+int gab_conv1d(const float* d_in, float* d_out, const float* d_ir, int ir_len, int tracks,
+               int bufsize, gab_stream_t stream) {
+    return gab_conv1d_shard(d_in, d_out, d_ir, ir_len, tracks, bufsize, 0, stream);
 }
 
 size_t gab_dwg_workspace_bytes(int n_waveguides, int bufsize) {

@@ -103,6 +103,23 @@ class Benchmark:
     def setup(self):
         check(lib.gab_bench_setup(self._h))
 
+    def set_shard(self, first_track, total_tracks):
+        """This benchmark (created with n_tracks = the shard's own count) computes tracks
+        [first_track, first_track + n_tracks) of a job of total_tracks (gab_bench_set_shard)."""
+        check(lib.gab_bench_set_shard(self._h, first_track, total_tracks))
+
+    def results(self):
+        """{name: (array copy, layout, per_track)} of what the last iteration left on the host."""
+        out = {}
+        for i in range(lib.gab_bench_result_count(self._h)):
+            name, data, n = C.c_char_p(), C.c_void_p(), C.c_size_t(0)
+            layout, per = C.c_int(0), C.c_size_t(0)
+            check(lib.gab_bench_result_array(self._h, i, C.byref(name), C.byref(data), C.byref(n),
+                                             C.byref(layout), C.byref(per)))
+            arr = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_float)), shape=(n.value,)).copy()
+            out[name.value.decode()] = (arr, layout.value, per.value)
+        return out
+
     def run(self, iterations=10, warmup=3):
         r = BenchResult()
         check(lib.gab_bench_run(self._h, iterations, warmup, C.byref(r)))

@@ -2,9 +2,16 @@
 
 Tracks are independent, so a job of `total` tracks is cut into contiguous
 shards, one per rank, and there is NO per-buffer collective.  The only exchange
-is one-time: the impulse-response bank, whose formula needs the GLOBAL track
-index and count, is generated once on rank 0 and broadcast (RCCL over xGMI on
-GPUs; gloo in the CPU tests), then every rank keeps its slice.
+is one-time: the Conv1D_accel impulse-response bank, whose formula needs the
+GLOBAL track index and count, is generated once on rank 0 and broadcast (RCCL
+over xGMI on GPUs; gloo in the CPU tests), then every rank keeps its slice.
+
+Every benchmark with independent tracks shards the same way through the harness
+(`shard_benchmark`): gain, GainStats, IIRFilter and FFT1D by rows; RndMemRead by
+tracks with the 512 MiB pool on every rank; Conv1D with the ceil((L-1)/B)
+preceding tracks' input rows as a halo (its golden convolves the FLAT input:
+cuda/bench_conv1d.cu:188-208).  DWG, modal and FDTD3D reduce into shared
+outputs: replicas only.
 """
 import numpy as np
 import torch
@@ -48,3 +55,36 @@ def scatter_columns(global_out, shard_out, rank, world, total_tracks, bufsize):
     lo, hi = shard_range(rank, world, total_tracks)
     global_out.reshape(bufsize, total_tracks)[:, lo:hi] = shard_out.reshape(bufsize, hi - lo)
     return global_out
+
+
+# registry names whose tracks are independent (gab_bench_set_shard accepts them)
+SHARDABLE = ("gain", "GainStats", "IIRFilter", "FFT1D", "RndMemRead", "Conv1D", "Conv1D_accel")
+
+
+def conv1d_halo_tracks(first_track, ir_len, bufsize):
+    """Input rows a Conv1D shard needs in front of its first track: the golden's flat indexing lets a
+    track's first L-1 outputs read the end of the preceding track(s)."""
+    return min(first_track, (ir_len - 1 + bufsize - 1) // bufsize)
+
+
+def shard_benchmark(name, rank, world, total_tracks, **cfg):
+    """The harness benchmark `name` for this rank's tracks of a total_tracks job (not yet set up)."""
+    if name not in SHARDABLE:
+        raise ValueError("%s has no independent tracks: replicas only" % name)
+    lo, hi = shard_range(rank, world, total_tracks)
+    b = harness.Benchmark(name, n_tracks=hi - lo, **cfg)
+    b.set_shard(lo, total_tracks)
+    return b
+
+
+def join_results(parts):
+    """Shard result dicts (Benchmark.results()) in rank order -> the whole job's arrays: track-major arrays
+    concatenate by rows, sample-major ones by columns."""
+    out = {}
+    for key in parts[0]:
+        layout, per = parts[0][key][1], parts[0][key][2]
+        if layout == 0:
+            out[key] = np.concatenate([p[key][0] for p in parts])
+        else:
+            out[key] = np.concatenate([p[key][0].reshape(per, -1) for p in parts], axis=1).ravel()
+    return out

@@ -120,6 +120,21 @@ public:
     virtual bool cpuGoldenWhole() { return false; }
     double timeCpuGolden(int threads, int* threads_used = nullptr);
 
+    // Channel shard (additive): this instance computes tracks [first_track, first_track + getTrackCount())
+    // of a job of total_tracks.  Inputs, impulse responses, playheads and goldens are then the GLOBAL job's rows — the
+    // one flat noise stream, the bank formulas with the global track index — so that the shards' results, put side
+    // by side, are the unsharded results bit for bit.  Call before setupBenchmark().  Benchmarks whose tracks are not
+    // independent (DWG, modal, FDTD3D reduce into shared outputs) throw std::invalid_argument from setupBenchmark().
+    void setShard(size_t first_track, size_t total_tracks);
+    bool isShard() const { return shard_total_ != 0; }
+    size_t shardFirstTrack() const { return shard_first_; }
+    size_t jobTracks() const { return shard_total_ ? shard_total_ : track_count_; }
+    virtual bool shardable() const { return false; }
+    // What an iteration leaves on the host, by name: `layout` 0 = track-major rows of per_track values, 1 = sample-major
+    // (value [per_track index][track]).  Shards' arrays concatenate by rows / by columns into the unsharded arrays.
+    struct ResultArray { const char* name; const float* data; size_t count; int layout; size_t per_track; };
+    virtual std::vector<ResultArray> resultArrays() const;
+
     // DAW-style pacing (metal-swift Core/GPUABenchmark.swift:90,358-392): when set, every
     // warm-up and timed iteration is followed by a wait for the next buffer slot.
     void setDawSimulator(const BenchmarkUtils::DAWSimulator& sim) { daw_simulator_ = sim; daw_enabled_ = true; }
@@ -162,6 +177,7 @@ protected:
     std::string benchmark_name_;
     size_t buffer_size_;
     size_t track_count_;
+    size_t shard_first_ = 0, shard_total_ = 0;      // shard_total_ == 0: the whole job
     float current_iteration_gpu_ms_ = 0.0f;
     hipStream_t stream_ = nullptr;             // all of this benchmark's device work
     BenchmarkUtils::DAWSimulator daw_simulator_;

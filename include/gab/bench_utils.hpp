@@ -187,6 +187,22 @@ void generateRandomAudioData(float* buffer, size_t samples, unsigned int seed = 
 // track-major stream the reference draws over ALL tracks (additive).
 void generateRandomAudioDataFrom(float* buffer, size_t samples, unsigned int seed, unsigned long long skip);
 
+// glibc's rand() (random_r.c TYPE_3: x^31 + x^3 + 1 seeded through the 16807 generator, 310 values discarded,
+// result = state >> 1) as an object: the stream srand(seed) starts — seed 1 is what an unseeded rand() gives a fresh
+// process, which is how the reference draws its FFT input (cuda/bench_fft.cu:37: one benchmark per process) — that
+// does not depend on what else in the process has called rand(), can be shared by no other thread, and can be
+// entered at any position (a channel shard skips the draws of the tracks before its own).  Additive.
+class GlibcRand {
+public:
+    static constexpr int kMax = 2147483647;
+    explicit GlibcRand(unsigned int seed = 1);
+    int next();
+    void discard(unsigned long long n) { while (n--) (void)next(); }
+private:
+    unsigned int r_[31];
+    int f_, b_;
+};
+
 enum class WindowType { RECTANGULAR, HAMMING, HANN, BLACKMAN };
 void generateImpulseResponse(float* buffer, int length, float frequency,
                              WindowType window_type = WindowType::HAMMING);

@@ -49,6 +49,7 @@ public:
     void performBenchmarkIteration() override;
     void validate(ValidationData& validation_data) override;
     bool cpuGoldenSlice(size_t first_track, size_t count) override;
+    bool shardable() const override { return true; }
     const float* cpuReference() const { return cpu_reference; }
 
 private:
@@ -70,6 +71,8 @@ public:
     void validate(ValidationData& validation_data) override;
     bool cpuGoldenSlice(size_t first_track, size_t count) override;
     size_t algorithmicBytes() const override;
+    bool shardable() const override { return true; }
+    std::vector<ResultArray> resultArrays() const override;
     const float* hostStats() const { return h_stats; }
     const float* cpuStatsReference() const { return cpu_stats_reference; }
 
@@ -137,6 +140,8 @@ public:
     void validate(ValidationData& validation_data) override;
     bool cpuGoldenSlice(size_t first_track, size_t count) override;
     size_t algorithmicBytes() const override;
+    bool shardable() const override { return true; }
+    std::vector<ResultArray> resultArrays() const override;
     // max over bins of |dre|+|dim| against a float64 DFT of the same input,
     // for the product output and for the reference-style fp32 golden
     double truthErrorOfOutput() const { return err_out_vs_truth_; }
@@ -176,6 +181,8 @@ public:
     bool cpuGoldenSlice(size_t first_track, size_t count) override;
     void resetState() override;
     size_t algorithmicBytes() const override;
+    bool shardable() const override { return true; }
+    std::vector<ResultArray> resultArrays() const override;
     const IIRCoefficients& coefficients() const { return *h_coeffs; }
 
 private:
@@ -205,13 +212,18 @@ public:
     void validate(ValidationData& validation_data) override;
     bool cpuGoldenSlice(size_t first_track, size_t count) override;
     size_t algorithmicBytes() const override;
+    bool shardable() const override { return true; }
     int irLength() const { return ir_length_; }
+    size_t haloTracks() const { return halo_tracks_; }      // a shard's input rows in front of its own (0: whole job)
 
 private:
     int ir_length_;
     float* h_ir_buf = nullptr;
     float* d_ir_buf = nullptr;
     float* cpu_reference = nullptr;
+    float* h_halo_in_ = nullptr;      // shards: [halo tracks | own tracks] of the flat input
+    float* d_halo_in_ = nullptr;
+    size_t halo_tracks_ = 0;
     size_t ir_buffer_size;
     size_t ir_buffer_bytes;
 };
@@ -237,6 +249,8 @@ public:
     bool cpuGoldenSlice(size_t first_track, size_t count) override;
     void resetState() override;
     size_t algorithmicBytes() const override;
+    bool shardable() const override { return true; }
+    std::vector<ResultArray> resultArrays() const override;
     // Multi-GPU runs: the impulse responses of this shard already lie on this device (its rows of the
     // bank that was broadcast over RCCL); setupBenchmark() then transforms those instead of uploading
     // its own copy.  The golden still uses the host formula, so validate() cross-checks the bank.
@@ -472,6 +486,8 @@ public:
     void validate(ValidationData& validation_data) override;
     bool cpuGoldenWhole() override;
     void resetState() override;
+    bool shardable() const override { return true; }
+    std::vector<ResultArray> resultArrays() const override;
 
 private:
     void initializePlayheads();
@@ -499,4 +515,8 @@ private:
 namespace gab {
 const std::vector<std::string>& benchmarkNames();
 std::unique_ptr<GPUABenchmark> createBenchmark(const std::string& name);
+// additive: the benchmarks whose tracks are independent, built for a channel shard of `tracks` tracks
+// (setShard() then places it in the job); nullptr / false for those that reduce into shared outputs
+std::unique_ptr<GPUABenchmark> createBenchmarkShard(const std::string& name, size_t tracks);
+bool benchmarkShards(const std::string& name);
 }  // namespace gab

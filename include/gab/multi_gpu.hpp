@@ -1,10 +1,13 @@
 // multi_gpu.hpp — one node, several GPUs, behind the reference driver (additive: the reference runs
 // one device; BASELINE configs[4] shards 8192 channels of Conv1D_accel over 8).
 //
-// One host thread per device.  Tracks are independent, so Conv1D_accel is cut into contiguous
-// channel shards (the remainder goes to the low ranks) and there is NO per-buffer collective.  The
-// one exchange is one-time: the impulse-response bank — its formula needs the GLOBAL track index
-// and count (cuda/bench_conv1d_accel.cu:152-173) — is generated once, uploaded to device 0 and
+// One host thread per device.  Tracks are independent, so gain, GainStats, IIRFilter, FFT1D, RndMemRead,
+// Conv1D and Conv1D_accel are cut into contiguous channel shards (the remainder goes to the low ranks)
+// and there is NO per-buffer collective: every rank takes its rows of the job's one input stream; Conv1D
+// also takes the few preceding tracks' rows its flat-index history reaches; RndMemRead keeps the whole
+// pool on every rank.  The one exchange is one-time and Conv1D_accel's: the impulse-response bank —
+// its formula needs the GLOBAL track index and count (cuda/bench_conv1d_accel.cu:152-173) — is
+// generated once, uploaded to device 0 and
 // broadcast with RCCL's C API (ncclCommInitAll + ncclBroadcast inside one group, xGMI between the
 // devices); every rank then transforms its own rows.  Benchmarks that reduce into shared outputs or
 // have no channel structure run as N independent replicas ("replicas only").
@@ -49,7 +52,8 @@ struct RankReport {
 
 struct MultiGpuReport {
     int gpus = 0;
-    bool sharded = false;            // channel shards (Conv1D_accel) vs replicas
+    bool sharded = false;            // channel shards (every benchmark with independent tracks) vs replicas
+    std::string partition;           // which form ran, in words (the "partition" member of --json)
     size_t total_tracks = 0;
     size_t ir_bank_bytes = 0;        // what the one-time broadcast moved (0: none)
     double ir_broadcast_ms = -1.0;   // ncclBroadcast of the bank incl. stream sync; < 0: no broadcast

@@ -86,6 +86,13 @@ int gab_iir_sequential(const float* d_in, float* d_out, const float* coeffs,
 int gab_conv1d(const float* d_in, float* d_out, const float* d_ir, int ir_len,
                int tracks, int bufsize, gab_stream_t stream);
 
+/* The same for a channel SHARD (additive): d_in starts halo_tracks tracks BEFORE the first of the
+ * `tracks` computed — the preceding tracks' rows, whose last ir_len-1 samples are the first track's history in
+ * the golden's flat indexing (halo_tracks = min(first global track, ceil((ir_len-1)/bufsize))); d_ir and d_out
+ * hold the computed tracks only.  halo_tracks = 0 is gab_conv1d.                                        */
+int gab_conv1d_shard(const float* d_in, float* d_out, const float* d_ir, int ir_len,
+                     int tracks, int bufsize, int halo_tracks, gab_stream_t stream);
+
 /* RndMemKernel (cuda/bench_rndmem.cu:7-20): out[T*i+t] = pool[playhead[t]+i].
  * pool_elems is used to range-check nothing on device; it is the caller's
  * promise that playhead[t]+bufsize <= pool_elems.  Bit-exact copy.           */
@@ -342,6 +349,18 @@ int  gab_bench_count(void);
 const char* gab_bench_name(int index);                 /* cuda/main.cu:84-100 */
 int  gab_bench_create(gab_bench** b, const char* name, const gab_bench_config* cfg);
 int  gab_bench_destroy(gab_bench* b);
+/* Channel shard (additive; BASELINE configs[4]): the benchmark — created with n_tracks = the shard's
+ * own track count — computes tracks [first_track, first_track + n_tracks) of a job of total_tracks: its inputs,
+ * impulse responses, playheads and goldens are the global job's rows, so that the shards' results side by side
+ * are the unsharded results bit for bit.  Before gab_bench_setup.  GAB_ERR_INVALID_ARG for benchmarks whose
+ * tracks are not independent (DWG, modal, FDTD3D: replicas only).                                        */
+int  gab_bench_set_shard(gab_bench* b, size_t first_track, size_t total_tracks);
+/* What the last iteration left on the host: result arrays by index (0 .. count-1).  layout 0: track-major rows of
+ * per_track floats (shards concatenate by rows), 1: sample-major [per_track][tracks] (shards concatenate by
+ * columns).  The pointers stay valid until the next iteration / destroy.                                */
+int  gab_bench_result_count(gab_bench* b);
+int  gab_bench_result_array(gab_bench* b, int index, const char** name, const float** data, size_t* count,
+                            int* layout, size_t* per_track);
 int  gab_bench_setup(gab_bench* b);
 int  gab_bench_run(gab_bench* b, int iterations, int warmup, gab_bench_result* out);
 int  gab_bench_validate(gab_bench* b, gab_bench_validation* out);

@@ -214,3 +214,71 @@ def test_harness_conv_batch_config(gab):
     assert v.status == 0 and v.max_error <= 1e-5, text
     assert b.algorithmic_bytes() == 12 * 4 * 64 * (2 * 512 + 2 * 4096) and r.gpu_median_ms > 0
     b.close()
+
+
+@pytest.mark.parametrize("name,total,cfg,iters", [
+    ("gain", 37, {}, 1),
+    ("GainStats", 37, {}, 1),
+    ("IIRFilter", 37, {}, 3),                               # state carries from iteration to iteration
+    ("FFT1D", 21, {}, 1),
+    ("RndMemRead", 29, {}, 4),                              # the playheads advance and wrap between iterations
+    ("Conv1D", 11, {"ir_length": 1024}, 1),                 # a halo of two tracks
+    ("Conv1D", 9, {"ir_length": 256}, 1),                   # one track
+    ("Conv1D", 7, {"ir_length": 1500, "buffer_size": 128}, 1),   # twelve tracks of history: more than some shards have before them
+    ("Conv1D_accel", 24, {"ir_length": 4096}, 3),
+])
+@pytest.mark.parametrize("world", [2, 3])
+def test_channel_shards_side_by_side_are_the_unsharded_results(gab, name, total, cfg, iters, world):
+    """SURVEY 8e on one device: every benchmark with independent tracks, run as `world` contiguous shards of the
+    job (gab_bench_set_shard: the job's input rows, banks with the global track index, playheads of the global
+    tracks, Conv1D's halo rows), leaves — side by side — exactly what the unsharded benchmark leaves: every result
+    array bit for bit (outputs, GainStats' statistics, the IIR state, RndMem after its playheads have advanced),
+    and every shard validates against its own CPU golden."""
+    from gpuaudiobench_amd import sharding
+    whole = gab.Benchmark(name, n_tracks=total, **cfg)
+    whole.setup()
+    whole.run(iterations=iters, warmup=0)
+    want = {k: v[0] for k, v in whole.results().items()}
+    whole.close()
+    parts = []
+    for rank in range(world):
+        b = sharding.shard_benchmark(name, rank, world, total, **cfg)
+        b.setup()
+        b.run(iterations=iters, warmup=0)
+        parts.append(b.results())
+        v, text = b.validate()
+        assert v.status == 0, (rank, text)
+        b.close()
+    got = sharding.join_results(parts)
+    assert set(got) == set(want)
+    for key in want:
+        assert got[key].shape == want[key].shape, key
+        assert np.array_equal(got[key].view(np.uint32), want[key].view(np.uint32)), (name, key)
+
+
+def test_benchmarks_that_reduce_into_shared_outputs_refuse_a_shard(gab):
+    for name in ("DWG1DAccel", "ModalFilterBank", "FDTD3D", "NoOp"):
+        b = gab.Benchmark(name, n_tracks=8)
+        with pytest.raises(gab.GabError):
+            b.set_shard(0, 16)
+        b.close()
+    b = gab.Benchmark("gain", n_tracks=8)
+    with pytest.raises(gab.GabError):
+        b.set_shard(12, 16)                                # [12, 20) does not lie inside 16 tracks
+    b.close()
+
+
+@pytest.mark.parametrize("name", ["Conv1D", "RndMemRead", "IIRFilter", "DWG1DAccel"])
+def test_driver_gpus_says_which_partition_ran(name):
+    """gpubench --gpus 1 walks the multi-device path (host thread, shard, setup under the lock) for every
+    benchmark; --json names the partition: channel shards for independent tracks, replicas otherwise."""
+    r = run_driver("--benchmark", name, "--gpus", "1", "--nTracks", "16", "--nRuns", "3", "--json", "--cpu-threads", "0")
+    assert r.returncode == 0, r.stdout[-2000:]
+    j = _json_of(r.stdout)
+    part = j["multi_gpu"]["partition"]
+    if name == "DWG1DAccel":
+        assert part == "replicas only"
+    else:
+        assert part.startswith("contiguous channel shards")
+        assert ("halo" in part) == (name == "Conv1D") and ("pool" in part) == (name == "RndMemRead")
+    assert j["multi_gpu"]["ranks"][0]["valid"] is True and j["multi_gpu"]["ranks"][0]["tracks"] == 16

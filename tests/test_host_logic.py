@@ -185,7 +185,7 @@ def test_driver_shard_arithmetic_and_flags_without_a_gpu():
         covered = 0
         for rank, ln in enumerate(got):
             lo, hi = sharding.shard_range(rank, world, total)
-            assert ln == "shard %d: tracks [%d, %d) = %d" % (rank, lo, hi, hi - lo)
+            assert ln == "shard %d: tracks [%d, %d) = %d" % (rank, lo, hi, hi - lo)        # (the default benchmark, RndMemRead, shards)
             a, b = C.c_size_t(0), C.c_size_t(0)
             assert _capi.lib.gab_shard_range(rank, world, total, C.byref(a), C.byref(b)) == 0
             assert (a.value, b.value) == (lo, hi) and lo == covered
@@ -200,3 +200,30 @@ def test_driver_shard_arithmetic_and_flags_without_a_gpu():
     help_text = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=60).stdout
     for flag in ("--gpus", "--fdtdSteps", "--validate-only", "--cpu-threads", "--print-shards", "--convBatch"):
         assert flag in help_text
+
+
+def test_conv1d_shards_carry_their_halo_rows_and_shared_outputs_stay_replicas():
+    """gpubench --print-shards for Conv1D names the input rows a shard needs in front of its own (its golden
+    convolves the FLAT input: the preceding ceil((L-1)/B) tracks, fewer at the job's start) — the same arithmetic
+    as sharding.conv1d_halo_tracks; benchmarks that reduce into shared outputs are replicas."""
+    import subprocess
+    from gpuaudiobench_amd import sharding
+    exe = os.path.join(os.path.dirname(os.path.abspath(gab.__file__)), "gpubench")
+    for world, total, L, B in [(3, 10, 1024, 512), (8, 256, 256, 512), (4, 9, 4000, 128), (2, 5, 1, 512)]:
+        r = subprocess.run([exe, "--benchmark", "Conv1D", "--print-shards", "--gpus", str(world), "--nTracks", str(total),
+                            "--irLength", str(L), "--bufferSize", str(B)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout
+        got = [ln for ln in r.stdout.splitlines() if ln.startswith("shard ")]
+        for rank, ln in enumerate(got):
+            lo, hi = sharding.shard_range(rank, world, total)
+            halo = sharding.conv1d_halo_tracks(lo, L, B)
+            assert halo == min(lo, -(-(L - 1) // B))
+            assert ln == "shard %d: tracks [%d, %d) = %d, input rows from track %d (halo %d)" % (rank, lo, hi, hi - lo, lo - halo, halo)
+    r = subprocess.run([exe, "--benchmark", "FDTD3D", "--print-shards", "--gpus", "4"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "replicas only" in r.stdout
+    assert set(sharding.SHARDABLE) == {"gain", "GainStats", "IIRFilter", "FFT1D", "RndMemRead", "Conv1D", "Conv1D_accel"}
+    # results side by side: rows for track-major arrays, columns for sample-major ones
+    a = {"o": (np.arange(6, dtype=np.float32), 0, 3), "s": (np.arange(4, dtype=np.float32).reshape(2, 2).ravel(), 1, 2)}
+    b = {"o": (np.arange(6, 9, dtype=np.float32), 0, 3), "s": (np.array([9, 8], np.float32), 1, 2)}
+    j = sharding.join_results([a, b])
+    assert j["o"].tolist() == list(range(9)) and j["s"].tolist() == [0, 1, 9, 2, 3, 8]
