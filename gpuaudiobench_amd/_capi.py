@@ -45,7 +45,7 @@ class FdtdParams(C.Structure):
 
 class BenchConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
-        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet", "modal_mode", "conv_batch")]
+        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet", "modal_mode", "conv_batch", "fdtd_form")]
 
 
 class BenchResult(C.Structure):
@@ -107,6 +107,8 @@ PROTOTYPES = {
     "gab_fdtd_process": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "gab_fdtd_copy_pressure": (_I, [_P, _P, _P]),
     "gab_fdtd_resident": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "gab_fdtd_set_form": (_I, [_P, _I]),
+    "gab_fdtd_status": (_I, [_P, _P]),
     "gab_fdtd_set_track_positions": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I]),
     "gab_fdtd_create_slab": (_I, [C.POINTER(_P), C.POINTER(FdtdParams), _I, _I]),
     "gab_fdtd_owns": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
@@ -118,6 +120,8 @@ PROTOTYPES = {
     "gab_fdtd_strip": (_I, [_P, C.POINTER(_P), C.POINTER(_I)]),
     "gab_generate_noise": (_I, [_P, _Z, C.c_uint]),
     "gab_shard_range": (_I, [_I, _I, _Z, C.POINTER(_Z), C.POINTER(_Z)]),
+    "gab_shard_range_aligned": (_I, [_I, _I, _Z, _Z, C.POINTER(_Z), C.POINTER(_Z)]),
+    "gab_shard_granule": (_Z, [C.c_char_p]),
     "gab_generate_conv1d_ir": (_I, [_P, _I, _Z, _Z, _Z]),
     "gab_generate_conv_accel_ir": (_I, [_P, _I, _Z, _Z, _Z]),
     "gab_calculate_statistics": (_I, [_P, _Z, C.POINTER(Statistics)]),

@@ -37,6 +37,8 @@ void printHelp() {
     printf("  --irLength [taps]   Impulse-response length for Conv1D / Conv1D_accel\n");
     printf("  --fdtdGrid [n]      FDTD3D grid edge including the boundary shell (default: 52)\n");
     printf("  --fdtdSteps [n]     FDTD3D: leapfrog steps per iteration (3 per sample: sets the buffer to ceil(n/3) samples)\n");
+    printf("  --fdtdForm [f]      FDTD3D: auto (the room resident in LDS where it fits, one launch per buffer; default) |\n");
+    printf("                      step (one launch per step: for a device shared with other work)\n");
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
     printf("  --convBatch [n]     Conv1D_accel: an iteration is ONE launch over n HBM-resident buffers (throughput mode,\n");
     printf("                      no per-iteration copies); default: one buffer per iteration with its copies\n");
@@ -259,6 +261,13 @@ int main(int argc, char** argv) {
         } else if (strcmp(argv[i], "--irLength") == 0) { if (!need("--irLength")) return 1; IR_LENGTH = atoi(argv[++i]); }
         else if (strcmp(argv[i], "--fdtdGrid") == 0) { if (!need("--fdtdGrid")) return 1; FDTD_GRID = atoi(argv[++i]); }
         else if (strcmp(argv[i], "--fdtdSteps") == 0) { if (!need("--fdtdSteps")) return 1; FDTD_STEPS = atoi(argv[++i]); }
+        else if (strcmp(argv[i], "--fdtdForm") == 0) {
+            if (!need("--fdtdForm")) return 1;
+            const char* m = argv[++i];
+            if (strcmp(m, "auto") == 0) FDTD_FORM = 0;
+            else if (strcmp(m, "step") == 0) FDTD_FORM = 1;
+            else { printf("Error: --fdtdForm takes auto or step\n"); return 1; }
+        }
         else if (strcmp(argv[i], "--gpus") == 0) {
             if (!need("--gpus")) return 1;
             g_gpus = atoi(argv[++i]);
@@ -318,7 +327,7 @@ int main(int argc, char** argv) {
         }
         const int L = IR_LENGTH > 0 ? IR_LENGTH : Conv1DBenchmark::DEFAULT_IR_LEN;
         for (int r = 0; r < world; ++r) {
-            const gab::ShardRange s = gab::shardRange(r, world, (size_t)NTRACKS);
+            const gab::ShardRange s = gab::shardRange(r, world, (size_t)NTRACKS, gab::shardGranule(which));
             if (which == "Conv1D") {          // its golden convolves the flat input: the preceding tracks' rows come along
                 const size_t halo = std::min(s.lo, ((size_t)L - 1 + (size_t)BUFSIZE - 1) / (size_t)BUFSIZE);
                 printf("shard %d: tracks [%zu, %zu) = %zu, input rows from track %zu (halo %zu)\n", r, s.lo, s.hi, s.count(),

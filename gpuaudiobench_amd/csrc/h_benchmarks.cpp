@@ -964,6 +964,7 @@ void FDTD3DBenchmark::setupBenchmark() {
     P.dt_over_rho_dx = gp.dt_over_rho_dx;
     P.rho_c2_dt_over_dx = gp.rho_c2_dt_over_dx;
     checkGab(gab_fdtd_create(&plan_, &gp), "gab_fdtd_create");
+    checkGab(gab_fdtd_set_form(plan_, FDTD_FORM == 1 ? GAB_FDTD_FORM_STEP : GAB_FDTD_FORM_AUTO), "gab_fdtd_set_form");
 
     h_input_signal = allocateHostBuffer<float>(n, benchmark_name_ + " host input signal");
     d_input_signal = allocateDeviceBuffer<float>(n, benchmark_name_ + " device input signal");
@@ -990,7 +991,9 @@ void FDTD3DBenchmark::performBenchmarkIteration() {
              "gab_fdtd_process");
     recordGpuDuration(g.finish());
     HIP_CHECK(hipMemcpyAsync(h_output_buffer, d_output_buffer, output_buffer_bytes, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    // the failing iteration throws (synchronizeAndCheck, cuda/bench_base.cu:177-179): synchronises, and reports a
+    // resident launch that gave up waiting for a neighbour workgroup
+    checkGab(gab_fdtd_status(plan_, stream_), "gab_fdtd_status");
 }
 
 // The reference golden is a non-physical placeholder compared at 1e-1

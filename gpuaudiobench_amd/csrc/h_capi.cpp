@@ -104,6 +104,7 @@ void gab_bench_default_config(gab_bench_config* c) {
     c->quiet = 1;
     c->modal_mode = 0;
     c->conv_batch = 0;
+    c->fdtd_form = 0;
 }
 
 int gab_bench_count(void) { return static_cast<int>(gab::benchmarkNames().size()); }
@@ -128,6 +129,7 @@ int gab_bench_create(gab_bench** out, const char* name, const gab_bench_config* 
         GAB_QUIET = c.quiet != 0;
         MODAL_REAL = c.modal_mode != 0;
         CONV_BATCH = c.conv_batch;
+        FDTD_FORM = c.fdtd_form == 1 ? 1 : 0;
         auto impl = gab::createBenchmark(name);
         if (!impl) return gab::bad_arg("gab_bench_create: unknown benchmark name");
         auto* b = new gab_bench;

@@ -16,14 +16,23 @@
 
 namespace gab {
 
-ShardRange shardRange(int rank, int world, size_t total_tracks) {
+ShardRange shardRange(int rank, int world, size_t total_tracks, size_t granule) {
     if (world < 1) throw std::invalid_argument("shardRange: world must be >= 1");
     if (rank < 0 || rank >= world) throw std::invalid_argument("shardRange: rank outside the world");
-    const size_t base = total_tracks / world, extra = total_tracks % world, r = static_cast<size_t>(rank);
+    if (granule < 1) throw std::invalid_argument("shardRange: granule must be >= 1");
+    // whole granules (the tracks a kernel packs into one transform must stay together), remainder to the low ranks
+    const size_t units = (total_tracks + granule - 1) / granule;
+    const size_t base = units / world, extra = units % world, r = static_cast<size_t>(rank);
     ShardRange s;
-    s.lo = r * base + std::min(r, extra);
-    s.hi = s.lo + base + (r < extra ? 1 : 0);
+    s.lo = std::min(total_tracks, (r * base + std::min(r, extra)) * granule);
+    s.hi = std::min(total_tracks, s.lo + (base + (r < extra ? 1 : 0)) * granule);
     return s;
+}
+
+size_t shardGranule(const std::string& benchmark) {
+    if (benchmark == "FFT1D") return 2;             // two tracks share one complex transform
+    if (benchmark == "Conv1D_accel") return 4;      // a duo of channel pairs shares a workgroup's transforms
+    return 1;
 }
 
 bool MultiGpuReport::ok() const {
@@ -193,7 +202,7 @@ MultiGpuReport runOnDevices(const MultiGpuConfig& cfg) {
     rep.total_tracks = rep.sharded ? static_cast<size_t>(NTRACKS) : static_cast<size_t>(NTRACKS) * cfg.gpus;
     rep.collective = "none";
     rep.ranks.resize(cfg.gpus);
-    if (rep.sharded && static_cast<size_t>(cfg.gpus) > rep.total_tracks)
+    if (rep.sharded && shardRange(cfg.gpus - 1, cfg.gpus, rep.total_tracks, shardGranule(cfg.benchmark)).count() == 0)
         throw std::invalid_argument("more GPUs than tracks");
 
     const int ir_len = IR_LENGTH > 0 ? IR_LENGTH : Conv1DAccelBenchmark::DEFAULT_IR_LEN;
@@ -229,7 +238,7 @@ MultiGpuReport runOnDevices(const MultiGpuConfig& cfg) {
             HIP_CHECK(hipSetDevice(r));
             std::unique_ptr<GPUABenchmark> b;
             if (rep.sharded) {
-                out.tracks = shardRange(r, cfg.gpus, rep.total_tracks);
+                out.tracks = shardRange(r, cfg.gpus, rep.total_tracks, shardGranule(cfg.benchmark));
                 b = createBenchmarkShard(cfg.benchmark, out.tracks.count());
                 b->setShard(out.tracks.lo, rep.total_tracks);
                 if (bank)
@@ -306,11 +315,17 @@ std::string multiGpuJson(const MultiGpuReport& r) {
 
 }  // namespace gab
 
-extern "C" int gab_shard_range(int rank, int world, size_t total_tracks, size_t* lo, size_t* hi) {
+extern "C" int gab_shard_range_aligned(int rank, int world, size_t total_tracks, size_t granule, size_t* lo, size_t* hi) {
     if (!lo || !hi) return gab::bad_arg("gab_shard_range: null pointer");
-    if (world < 1 || rank < 0 || rank >= world) return gab::bad_arg("gab_shard_range: rank outside the world");
-    const gab::ShardRange s = gab::shardRange(rank, world, total_tracks);
+    if (world < 1 || rank < 0 || rank >= world || granule < 1) return gab::bad_arg("gab_shard_range: rank outside the world");
+    const gab::ShardRange s = gab::shardRange(rank, world, total_tracks, granule);
     *lo = s.lo;
     *hi = s.hi;
     return GAB_OK;
 }
+
+extern "C" int gab_shard_range(int rank, int world, size_t total_tracks, size_t* lo, size_t* hi) {
+    return gab_shard_range_aligned(rank, world, total_tracks, 1, lo, hi);
+}
+
+extern "C" size_t gab_shard_granule(const char* benchmark) { return benchmark ? gab::shardGranule(benchmark) : 1; }

@@ -30,6 +30,7 @@ int CONV_STREAMING = 1;
 int MODAL_REAL = 0;
 int CONV_BATCH = 0;
 int FDTD_STEPS = 0;
+int FDTD_FORM = 0;
 int CPU_THREADS = 0;
 bool GAB_QUIET = false;
 

@@ -70,13 +70,16 @@ __global__ void fdtd_add_source_kernel(float* __restrict__ p, size_t src, const 
     if (blockIdx.x == 0 && threadIdx.x == 0) p[src] = __fadd_rn(p[src], inj[s]);
 }
 
-// out[t*B + s] = strip[s] for every track (the receiver value is track-independent)
+// out[t*B + s] = strip[s] for every track (the receiver value is track-independent).  `gave_up`, when given, is the
+// resident kernel's timeout word: a launch that stopped waiting for a neighbour leaves undefined fields and an
+// undefined strip, so THAT call's output is NaN from the first sample on — unmistakable — instead of plausible.
 __global__ void fdtd_broadcast_kernel(const float* __restrict__ strip, float* __restrict__ out, int T,
-                                      int B, int first, int count) {
+                                      int B, int first, int count, const unsigned* __restrict__ gave_up = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int t = blockIdx.y;
     if (i >= count) return;
-    out[(size_t)t * B + first + i] = strip[first + i];
+    const bool bad = gave_up != nullptr && *gave_up != 0;
+    out[(size_t)t * B + first + i] = bad ? __uint_as_float(0x7fc00000u) : strip[first + i];
 }
 
 // Track-dependent source / receiver cells (gab_fdtd_set_track_positions): between two samples,
@@ -934,7 +937,8 @@ struct gab_fdtd_plan {
     unsigned* res_xbuf = nullptr;       // [2 parities][workgroups][4 faces][fr rows][128 granules {pressure, tag}] + the timeout word
     size_t res_xbuf_dwords = 0;
     unsigned res_tag = 0;               // steps the resident kernel has run on this plan: the exchange tags go on from here
-    unsigned* res_timeout_host = nullptr;   // pinned copy of the timeout word, checked by the next call
+    unsigned* res_timeout_host = nullptr;   // pinned copy of the timeout word (copied behind every resident launch)
+    bool form_step = false;             // gab_fdtd_set_form(GAB_FDTD_FORM_STEP): never the resident kernel
     hipStream_t capture_stream = nullptr;   // capture target (the caller's stream may be the null stream)
     std::vector<std::pair<FdtdGraphKey, hipGraphExec_t>> graphs;   // small LRU, newest last
 };
@@ -1020,7 +1024,13 @@ void choose_resident_geometry(gab_fdtd_plan* f) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return;
-    const int lds_max = 160 * 1024;                              // gfx950: 160 KB of LDS per CU (and per workgroup)
+    // the kernel is written for gfx950 (sc1 hand-off, 160 KB of LDS per workgroup): any other device, or one that
+    // cannot give a workgroup the image, takes the step kernels
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return;
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds_max <= 0) return;
+    lds_max = std::min(lds_max, 160 * 1024);
     long best_w = 0, best_surface = 0;
     for (int bz = 2; bz <= 32; ++bz)
         for (int by = 2; by <= 32; ++by) {
@@ -1040,6 +1050,46 @@ void choose_resident_geometry(gab_fdtd_plan* f) {
                 f->res_lds_bytes = floats * sizeof(float);
             }
         }
+}
+
+// The resident form's one-time set-up: the exchange buffer, the kernel's LDS allowance and the proof that every one
+// of its workgroups fits the device at once (the kernel's neighbours wait for each other: a grid the device can only
+// hold in two rounds would wait for good).  Anything that fails leaves the plan on the step kernels.
+bool prepare_resident(gab_fdtd_plan* f, hipStream_t s) {
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        if (f->res_xbuf) { (void)hipFree(f->res_xbuf); f->res_xbuf = nullptr; }
+        f->res_rpt = 0;
+        return false;
+    };
+    const void* fn = f->res_rpt == 1 ? reinterpret_cast<const void*>(gab::fdtd_resident_kernel<1>)
+                                     : reinterpret_cast<const void*>(gab::fdtd_resident_kernel<2>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->res_lds_bytes) != hipSuccess) return give_up();
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, gab::kResThreads, f->res_lds_bytes) != hipSuccess)
+        return give_up();
+    const size_t wgs = (size_t)f->rgeom.gy * f->rgeom.gz;
+    if (per_cu < 1 || wgs > (size_t)per_cu * (size_t)cus) return give_up();
+    f->res_xbuf_dwords = (size_t)2 * wgs * 4 * f->rgeom.fr * gab::kResRowDwords;
+    if (hipMalloc(&f->res_xbuf, sizeof(unsigned) * (f->res_xbuf_dwords + 4)) != hipSuccess) return give_up();
+    if (hipMemsetAsync(f->res_xbuf, 0, sizeof(unsigned) * (f->res_xbuf_dwords + 4), s) != hipSuccess) return give_up();   // tag 0 = never written
+    if (!f->res_timeout_host) {
+        if (hipHostMalloc(&f->res_timeout_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return give_up();
+        *f->res_timeout_host = 0;
+    }
+    return true;
+}
+
+// A resident launch that gave up waiting left its word in the pinned copy (it travels behind every resident launch on
+// the launch's stream).  Consumes it: the plan takes the step kernels from now on.  0, or 1 + the step it stopped at.
+unsigned take_resident_timeout(gab_fdtd_plan* f) {
+    if (!f->res_timeout_host || *f->res_timeout_host == 0) return 0;
+    const unsigned at = *f->res_timeout_host;
+    *f->res_timeout_host = 0;
+    f->resident = false;
+    return at;
 }
 
 int create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int z_begin, int z_end, const char* who) {
@@ -1198,6 +1248,7 @@ int gab_fdtd_create_slab(gab_fdtd_plan** out, const gab_fdtd_params* params, int
 int gab_fdtd_destroy(gab_fdtd_plan* f) {
     if (!f) return GAB_OK;
     (void)hipDeviceSynchronize();
+    const unsigned gave_up_at = take_resident_timeout(f);     // a last call nobody asked about
     for (auto& g : f->graphs) (void)hipGraphExecDestroy(g.second);
     if (f->capture_stream) (void)hipStreamDestroy(f->capture_stream);
     free_fields(f->cur_real);
@@ -1208,6 +1259,11 @@ int gab_fdtd_destroy(gab_fdtd_plan* f) {
     if (f->res_timeout_host) (void)hipHostFree(f->res_timeout_host);
     free_track_positions(f);
     delete f;
+    if (gave_up_at) {
+        gab::set_last_error("gab_fdtd_destroy: the plan's last LDS-resident launch had timed out at step " + std::to_string(gave_up_at - 1) +
+                            " waiting for a neighbour workgroup; that call's output was NaN");
+        return GAB_ERR_RUNTIME;
+    }
     return GAB_OK;
 }
 
@@ -1217,6 +1273,11 @@ int gab_fdtd_reset(gab_fdtd_plan* f, gab_stream_t stream) {
         hipStream_t s = gab::as_stream(stream);
         zero_fields(f->cur_real, *f, s);
         zero_fields(f->nxt_real, *f, s);
+        if (const unsigned at = take_resident_timeout(f)) {       // the fields are defined again; the caller still hears of it
+            gab::set_last_error("gab_fdtd_reset: an earlier LDS-resident launch had timed out at step " + std::to_string(at - 1) +
+                                " waiting for a neighbour workgroup (its output was NaN); the plan is reset and takes the step kernels from now on");
+            return GAB_ERR_RUNTIME;
+        }
         return GAB_OK;
     });
 }
@@ -1230,9 +1291,30 @@ extern "C" int gab_debug_fdtd_phases(unsigned long long* h_out) {
 }
 #endif
 
+int gab_fdtd_set_form(gab_fdtd_plan* f, int form) {
+    if (!f) return gab::bad_arg("gab_fdtd_set_form: null plan");
+    if (form != GAB_FDTD_FORM_AUTO && form != GAB_FDTD_FORM_STEP) return gab::bad_arg("gab_fdtd_set_form: unknown form");
+    f->form_step = form == GAB_FDTD_FORM_STEP;
+    return GAB_OK;
+}
+
+int gab_fdtd_status(gab_fdtd_plan* f, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!f) return gab::bad_arg("gab_fdtd_status: null plan");
+        GAB_HIP_CHECK(hipStreamSynchronize(gab::as_stream(stream)));
+        if (const unsigned at = take_resident_timeout(f)) {
+            gab::set_last_error("gab_fdtd_status: the LDS-resident launch of the last gab_fdtd_process timed out at step " +
+                                std::to_string(at - 1) + " waiting for a neighbour workgroup (device shared with other work?); its "
+                                "output is NaN and the plan's fields are undefined: reset it (it takes the step kernels from now on)");
+            return GAB_ERR_RUNTIME;
+        }
+        return GAB_OK;
+    });
+}
+
 int gab_fdtd_resident(const gab_fdtd_plan* f, int* resident, int* workgroups) {
     if (!f) return gab::bad_arg("gab_fdtd_resident: null plan");
-    const bool r = f->resident && f->res_rpt > 0 && !f->pos_tracks;
+    const bool r = f->resident && !f->form_step && f->res_rpt > 0 && !f->pos_tracks;
     if (resident) *resident = r ? 1 : 0;
     if (workgroups) *workgroups = r ? f->rgeom.gy * f->rgeom.gz : 0;
     return GAB_OK;
@@ -1259,10 +1341,7 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         // launch per SAMPLE: three steps inside a tile (fdtd_sample_tile_kernel).  Measured per step:
         // 20^3 1.98 vs 3.8 us, 32^3 2.11 vs 3.7, 52^3 3.49 vs 4.2, 56^3 3.59; at 64^3 the one-step chain wins
         // a previous resident launch that gave up waiting for a neighbour workgroup left its word here
-        if (f->res_timeout_host && *f->res_timeout_host) {
-            const unsigned at = *f->res_timeout_host;
-            *f->res_timeout_host = 0;
-            f->resident = false;                                     // the step kernels from now on
+        if (const unsigned at = take_resident_timeout(f)) {
             gab::set_last_error("gab_fdtd_process: the LDS-resident kernel of the PREVIOUS call timed out at step " +
                                 std::to_string(at - 1) + " waiting for a neighbour workgroup (device shared with other "
                                 "work?); the plan's fields are undefined, reset it");
@@ -1271,18 +1350,8 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
         // (not inside a caller's stream capture: the exchange tags are a launch argument that a replay would freeze)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &cap);
-        const bool resident = f->resident && f->res_rpt > 0 && !f->pos_tracks && cap == hipStreamCaptureStatusNone;
-        if (resident && !f->res_xbuf) {
-            const size_t wgs = (size_t)f->rgeom.gy * f->rgeom.gz;
-            f->res_xbuf_dwords = (size_t)2 * wgs * 4 * f->rgeom.fr * gab::kResRowDwords;
-            GAB_HIP_CHECK(hipMalloc(&f->res_xbuf, sizeof(unsigned) * (f->res_xbuf_dwords + 4)));
-            GAB_HIP_CHECK(hipMemsetAsync(f->res_xbuf, 0, sizeof(unsigned) * (f->res_xbuf_dwords + 4), s));   // tag 0 = never written
-            GAB_HIP_CHECK(hipHostMalloc(&f->res_timeout_host, sizeof(unsigned), hipHostMallocDefault));
-            *f->res_timeout_host = 0;
-            const void* fn = f->res_rpt == 1 ? reinterpret_cast<const void*>(gab::fdtd_resident_kernel<1>)
-                                             : reinterpret_cast<const void*>(gab::fdtd_resident_kernel<2>);
-            GAB_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->res_lds_bytes));
-        }
+        bool resident = f->resident && !f->form_step && f->res_rpt > 0 && !f->pos_tracks && cap == hipStreamCaptureStatusNone;
+        if (resident && !f->res_xbuf) resident = prepare_resident(f, s);     // false: this device cannot hold the grid at once
         const bool by_sample = f->sample_tiles && !f->pos_tracks && P.steps_per_sample == 3 && f->z_begin == 0 &&
                                f->z_end == P.nz && P.nx <= 56 && P.ny <= 56 && P.nz <= 56;
         // enqueue the whole chain on `q`, walking local copies of the ping-pong pair
@@ -1326,7 +1395,7 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
                 GAB_HIP_CHECK(hipMemcpyAsync(f->res_timeout_host, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, q));
                 dim3 bgrid((n_samples + 127) / 128, tracks);
                 gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
-                                                                n_samples);
+                                                                n_samples, tmo);
                 return;
             }
             if (by_sample) {
@@ -1532,6 +1601,11 @@ int gab_fdtd_strip(gab_fdtd_plan* f, float** d_strip, int* capacity) {
 int gab_fdtd_copy_pressure(gab_fdtd_plan* f, float* d_dst, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!f || !d_dst) return gab::bad_arg("gab_fdtd_copy_pressure: null pointer");
+        if (f->res_timeout_host && *f->res_timeout_host) {           // left in place: the next process / status / reset consumes it
+            gab::set_last_error("gab_fdtd_copy_pressure: an LDS-resident launch timed out waiting for a neighbour workgroup; "
+                                "the plan's fields are undefined, reset it");
+            return GAB_ERR_RUNTIME;
+        }
         const size_t sxy = (size_t)f->P.nx * f->P.ny;
         GAB_HIP_CHECK(hipMemcpyAsync(d_dst, f->cur_real.p + sxy, sxy * (size_t)(f->z_end - f->z_begin) * sizeof(float),
                                      hipMemcpyDeviceToDevice, gab::as_stream(stream)));

@@ -259,6 +259,15 @@ class FdtdPlan:
                                    n_samples, _stream()))
         return out
 
+    def set_form(self, form):
+        """"auto" (resident in LDS where the room fits) or "step" (one launch per step): gab_fdtd_set_form."""
+        check(lib.gab_fdtd_set_form(self._h, {"auto": 0, "step": 1}[form]))
+
+    def status(self):
+        """Synchronises the current stream; raises GabError if the last process() call's resident launch
+        gave up waiting for a neighbour workgroup: gab_fdtd_status."""
+        check(lib.gab_fdtd_status(self._h, _stream()))
+
     def resident(self):
         """(takes the LDS-resident whole-buffer kernel, its workgroups): gab_fdtd_resident."""
         r, w = C.c_int(0), C.c_int(0)

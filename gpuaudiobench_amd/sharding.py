@@ -19,13 +19,23 @@ import torch
 from . import harness
 
 
-def shard_range(rank, world, total_tracks):
-    """Contiguous [lo, hi) of this rank; the remainder goes to the low ranks."""
+def shard_range(rank, world, total_tracks, granule=1):
+    """Contiguous [lo, hi) of this rank, cut at multiples of `granule` tracks; the remainder goes to
+    the low ranks.  (gab_shard_range_aligned; the C++ driver's gab::shardRange.)"""
     if not (0 <= rank < world):
         raise ValueError("rank %d outside world %d" % (rank, world))
-    base, extra = divmod(total_tracks, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+    units = -(-total_tracks // granule)
+    base, extra = divmod(units, world)
+    lo = min(total_tracks, (rank * base + min(rank, extra)) * granule)
+    return lo, min(total_tracks, lo + (base + (1 if rank < extra else 0)) * granule)
+
+
+# tracks a kernel packs into one transform must stay in one shard for the bits to be the unsharded ones
+GRANULE = {"FFT1D": 2, "Conv1D_accel": 4}
+
+
+def shard_granule(name):
+    return GRANULE.get(name, 1)
 
 
 def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=0):
@@ -71,7 +81,7 @@ def shard_benchmark(name, rank, world, total_tracks, **cfg):
     """The harness benchmark `name` for this rank's tracks of a total_tracks job (not yet set up)."""
     if name not in SHARDABLE:
         raise ValueError("%s has no independent tracks: replicas only" % name)
-    lo, hi = shard_range(rank, world, total_tracks)
+    lo, hi = shard_range(rank, world, total_tracks, shard_granule(name))
     b = harness.Benchmark(name, n_tracks=hi - lo, **cfg)
     b.set_shard(lo, total_tracks)
     return b

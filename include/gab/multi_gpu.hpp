@@ -31,7 +31,11 @@ struct ShardRange {
 };
 // Contiguous [lo, hi) of `rank` out of `world`; the remainder goes to the low ranks.  Throws
 // std::invalid_argument for a rank outside the world or a world < 1.
-ShardRange shardRange(int rank, int world, size_t total_tracks);
+// `granule`: tracks that must stay together — FFT1D transforms two tracks in one complex transform and Conv1D_accel
+// four channels in one workgroup's, so their bits depend on which tracks share one: shards of those are cut at
+// multiples of shardGranule() and then reproduce the unsharded results bit for bit.
+ShardRange shardRange(int rank, int world, size_t total_tracks, size_t granule = 1);
+size_t shardGranule(const std::string& benchmark);
 
 struct MultiGpuConfig {
     std::string benchmark;       // registry name

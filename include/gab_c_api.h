@@ -234,11 +234,24 @@ int gab_fdtd_process(gab_fdtd_plan* plan, const float* d_in, float* d_out,
  * resident in LDS and registers, one block of rows per workgroup, the blocks' boundary pressures handed to the
  * neighbours through memory every step (same bits as the step kernels, 4x their speed at 128^3).  It needs
  * every workgroup on the device at once (resident launches of one process are chained per device, whatever
- * their streams; other processes' kernels are not known): a workgroup that waits about a second for a neighbour gives up, the
- * NEXT call returns GAB_ERR_RUNTIME and the plan uses the step kernels from then on.  Larger rooms, z-slabs,
+ * their streams; other processes' kernels are not known; plan creation checks that the device can hold the whole grid at
+ * once): a workgroup that waits about a second for a neighbour gives up, that call's output is NaN, gab_fdtd_status (or
+ * the next call on the plan) returns GAB_ERR_RUNTIME and the plan uses the step kernels from then on.  Larger rooms, z-slabs,
  * per-track positions and calls inside a stream capture use the step kernels.
  * *resident = 1 when the next call (outside a capture) takes the resident form, *workgroups = its grid. */
 int gab_fdtd_resident(const gab_fdtd_plan* plan, int* resident, int* workgroups);
+/* A host that shares the device with other work can decline the resident form: STEP = one launch per step (per
+ * sample for rooms up to 56^3), no workgroup ever waits for another; AUTO (default) = resident where it fits.  Same
+ * bits either way.  Takes effect with the next gab_fdtd_process.                                          */
+#define GAB_FDTD_FORM_AUTO 0
+#define GAB_FDTD_FORM_STEP 1
+int gab_fdtd_set_form(gab_fdtd_plan* plan, int form);
+/* Errors at the call that failed (the reference throws from the failing iteration: synchronizeAndCheck,
+ * cuda/bench_base.cu:177-179).  Synchronises `stream` and returns GAB_ERR_RUNTIME if the resident launch of the
+ * last gab_fdtd_process on it gave up waiting for a neighbour workgroup.  That call's output is NaN in every
+ * sample (never plausible audio); the plan then takes the step kernels and wants a gab_fdtd_reset.  Without this
+ * call the same error is returned by the NEXT gab_fdtd_process, gab_fdtd_reset or gab_fdtd_destroy.        */
+int gab_fdtd_status(gab_fdtd_plan* plan, gab_stream_t stream);
 /* Track-dependent source and receiver cells — announced and never done by the Metal port
  * ("can be made track-dependent later", kernels_fdtd3d.metal:184,217).  src_xyz / rcv_xyz: HOST
  * arrays, tracks x (x, y, z).  From then on gab_fdtd_process (with that many tracks) adds
@@ -294,6 +307,11 @@ int gab_generate_conv_accel_ir(float* h_ir, int ir_len, size_t track_offset,
 /* Channel shards of a multi-GPU job (additive; BASELINE configs[4]): the contiguous range
  * [*lo, *hi) of `rank` out of `world`, the remainder going to the low ranks.  Host arithmetic.  */
 int gab_shard_range(int rank, int world, size_t total_tracks, size_t* lo, size_t* hi);
+/* The same cut at multiples of `granule` tracks, and the granule a benchmark (registry name) needs: FFT1D packs two
+ * tracks into one complex transform (2), Conv1D_accel four channels into one workgroup's (4) — their bits depend on
+ * which tracks share a transform, so their shards keep those groups whole; every other benchmark 1.            */
+int gab_shard_range_aligned(int rank, int world, size_t total_tracks, size_t granule, size_t* lo, size_t* hi);
+size_t gab_shard_granule(const char* benchmark);
 
 /* calculateStatistics (cuda/bench_utils.cu:358-414): mean, median, sample
  * std-dev, min, max, linearly interpolated p95/p99.                          */
@@ -329,6 +347,7 @@ typedef struct {
     int    conv_batch;      /* Conv1D_accel: <=1 one buffer per iteration with its copies (the
                                reference); n: n HBM-resident buffers per iteration in ONE
                                gab_conv_process_batch launch (throughput mode)           */
+    int    fdtd_form;       /* FDTD3D: GAB_FDTD_FORM_AUTO (0) | GAB_FDTD_FORM_STEP (1)              */
 } gab_bench_config;
 
 typedef struct {

@@ -222,6 +222,22 @@ def test_conv1d_shards_carry_their_halo_rows_and_shared_outputs_stay_replicas():
     r = subprocess.run([exe, "--benchmark", "FDTD3D", "--print-shards", "--gpus", "4"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "replicas only" in r.stdout
     assert set(sharding.SHARDABLE) == {"gain", "GainStats", "IIRFilter", "FFT1D", "RndMemRead", "Conv1D", "Conv1D_accel"}
+    # shards of benchmarks that pack tracks into one transform are cut at multiples of the pack
+    import ctypes as C
+    from gpuaudiobench_amd import _capi
+    for name, g in (("FFT1D", 2), ("Conv1D_accel", 4), ("gain", 1), ("Conv1D", 1)):
+        assert sharding.shard_granule(name) == g == _capi.lib.gab_shard_granule(name.encode())
+    for world, total, g in [(2, 21, 2), (3, 52, 4), (8, 8192, 4), (3, 7, 4), (4, 10, 1)]:
+        covered = 0
+        for rank in range(world):
+            lo, hi = sharding.shard_range(rank, world, total, g)
+            a, b = C.c_size_t(0), C.c_size_t(0)
+            assert _capi.lib.gab_shard_range_aligned(rank, world, total, g, C.byref(a), C.byref(b)) == 0
+            assert (a.value, b.value) == (lo, hi) and lo == covered and (lo % g == 0 or lo == total)
+            covered = hi
+        assert covered == total
+    r = subprocess.run([exe, "--benchmark", "FFT1D", "--print-shards", "--gpus", "2", "--nTracks", "21"], capture_output=True, text=True, timeout=60)
+    assert "shard 0: tracks [0, 12) = 12" in r.stdout and "shard 1: tracks [12, 21) = 9" in r.stdout
     # results side by side: rows for track-major arrays, columns for sample-major ones
     a = {"o": (np.arange(6, dtype=np.float32), 0, 3), "s": (np.arange(4, dtype=np.float32).reshape(2, 2).ravel(), 1, 2)}
     b = {"o": (np.arange(6, 9, dtype=np.float32), 0, 3), "s": (np.array([9, 8], np.float32), 1, 2)}
