@@ -986,11 +986,14 @@ void FDTD3DBenchmark::resetState() { checkGab(gab_fdtd_reset(plan_, stream_), "g
 void FDTD3DBenchmark::performBenchmarkIteration() {
     HIP_CHECK(hipMemcpyAsync(d_input_signal, h_input_signal, input_signal_bytes, hipMemcpyHostToDevice, stream_));
     ScopedGpuTimer g(stream_);
-    checkGab(gab_fdtd_process(plan_, d_input_signal, d_output_buffer, static_cast<int>(getTrackCount()),
+    // The output is a few KB (the receiver's strip repeated per track): the last kernel writes it straight into the
+    // pinned host buffer instead of a device buffer plus a copy command.  (A rocprofv3 HIP trace of this benchmark
+    // found the one 7 ms iteration round 3 reported inside that hipMemcpyAsync — a one-off stall of the runtime on
+    // the host, the kernel before it took its usual 2.8 ms: profiles/r04_fdtd_outlier.md.)
+    checkGab(gab_fdtd_process(plan_, d_input_signal, h_output_buffer, static_cast<int>(getTrackCount()),
                               static_cast<int>(getBufferSize()), 0, static_cast<int>(getBufferSize()), stream_),
              "gab_fdtd_process");
     recordGpuDuration(g.finish());
-    HIP_CHECK(hipMemcpyAsync(h_output_buffer, d_output_buffer, output_buffer_bytes, hipMemcpyDeviceToHost, stream_));
     // the failing iteration throws (synchronizeAndCheck, cuda/bench_base.cu:177-179): synchronises, and reports a
     // resident launch that gave up waiting for a neighbour workgroup
     checkGab(gab_fdtd_status(plan_, stream_), "gab_fdtd_status");

@@ -74,9 +74,14 @@ __global__ void fdtd_add_source_kernel(float* __restrict__ p, size_t src, const 
 // resident kernel's timeout word: a launch that stopped waiting for a neighbour leaves undefined fields and an
 // undefined strip, so THAT call's output is NaN from the first sample on — unmistakable — instead of plausible.
 __global__ void fdtd_broadcast_kernel(const float* __restrict__ strip, float* __restrict__ out, int T,
-                                      int B, int first, int count, const unsigned* __restrict__ gave_up = nullptr) {
+                                      int B, int first, int count, const unsigned* __restrict__ gave_up = nullptr,
+                                      unsigned* __restrict__ gave_up_host = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int t = blockIdx.y;
+    // the pinned copy of the word travels with this kernel (no copy command: a 4-byte engine copy per call costs more
+    // than the store, and copy commands are where the runtime's one-off multi-millisecond stalls were found)
+    if (gave_up_host != nullptr && i == 0 && t == 0 && *gave_up != 0)
+        __hip_atomic_store(gave_up_host, *gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i >= count) return;
     const bool bad = gave_up != nullptr && *gave_up != 0;
     out[(size_t)t * B + first + i] = bad ? __uint_as_float(0x7fc00000u) : strip[first + i];
@@ -1392,10 +1397,9 @@ int gab_fdtd_process(gab_fdtd_plan* f, const float* d_in, float* d_out, int trac
                 g_resident_chain.run(q, [&]() { if (f->res_rpt == 1) GAB_RESIDENT_LAUNCH(1); else GAB_RESIDENT_LAUNCH(2); });
 #undef GAB_RESIDENT_LAUNCH
                 f->res_tag += (unsigned)n_samples * (unsigned)P.steps_per_sample;
-                GAB_HIP_CHECK(hipMemcpyAsync(f->res_timeout_host, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, q));
                 dim3 bgrid((n_samples + 127) / 128, tracks);
                 gab::fdtd_broadcast_kernel<<<bgrid, 128, 0, q>>>(f->strip, d_out, tracks, bufsize, first_sample,
-                                                                n_samples, tmo);
+                                                                n_samples, tmo, f->res_timeout_host);
                 return;
             }
             if (by_sample) {

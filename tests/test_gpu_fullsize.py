@@ -197,9 +197,11 @@ def test_conv_accel_reset_then_launch_on_another_stream_without_host_sync(gab, o
 def test_fdtd_c4_as_baseline_states_it(gab, orc):
     """BASELINE C4: 128^3 grid, 1000 leapfrog steps (334 samples x 3 steps = 1002).  Output and
     pressure field bit-exact against orc_fdtd(fused) — the restated kernels of
-    cuda/bench_fdtd3d.cu:14-139 in the order of runFDTD3DTimeStep (:384-438).  By then the front
-    has crossed the room several times: the receiver hears it and the planes next to the damped shell hold
-    developed values, which the LDS-halo kernels (the ones this grid takes) must reproduce on every face."""
+    cuda/bench_fdtd3d.cu:14-139 in the order of runFDTD3DTimeStep (:384-438) — for BOTH forms the room can take:
+    the LDS-resident kernel (gab_fdtd_set_form AUTO: what this grid takes by default, one launch per call) and the
+    step kernels (STEP: one launch per step, the LDS-halo kernels — also what a plan falls back to after a resident
+    launch has timed out), each for the full 1002 steps.  By then the front has crossed the room several times: the
+    receiver hears it and the planes next to the damped shell hold developed values on every face."""
     import torch
     n, T, B = 128, 8, 334
     P = orc.fdtd_params(n)
@@ -207,17 +209,24 @@ def test_fdtd_c4_as_baseline_states_it(gab, orc):
     x = orc.Rand(1).bipolar(T * B)
     grids = orc.fdtd_grids(P)
     ref = np.zeros(T * B, np.float32)
-    plan = gab.FdtdPlan(G)
-    out = torch.zeros(T * B, device="cuda")
-    xd = dev(x)
-    for first, cnt in ((0, 100), (100, 134), (234, 100)):        # state carries across calls
-        plan.process(xd, out, T, B, first, cnt)
+    calls = ((0, 100), (100, 134), (234, 100))                   # state carries across calls
+    for first, cnt in calls:
         orc.fdtd(P, grids, x, ref, T, B, first, cnt, fused=True)
-    got = host(out)
-    assert np.array_equal(bits(got), bits(ref))
     p_ref = grids[0].reshape(n, n, n)
-    p_got = host(plan.pressure())
-    assert np.array_equal(bits(p_got.ravel()), bits(p_ref.ravel()))
+    xd = dev(x)
+    for form in ("auto", "step"):
+        plan = gab.FdtdPlan(G)
+        plan.set_form(form)
+        assert plan.resident()[0] == (form == "auto")
+        out = torch.zeros(T * B, device="cuda")
+        for first, cnt in calls:
+            plan.process(xd, out, T, B, first, cnt)
+            plan.status()                                        # synchronises; raises if the launch had given up
+        got = host(out)
+        assert np.array_equal(bits(got), bits(ref)), form
+        p_got = host(plan.pressure())
+        assert np.array_equal(bits(p_got.ravel()), bits(p_ref.ravel())), form
+        plan.close()
     # the run is long enough to mean something
     assert np.count_nonzero(ref.reshape(T, B)[0]) > 200          # the receiver hears the source
     assert np.abs(ref).max() > 1e-6
@@ -228,7 +237,24 @@ def test_fdtd_c4_as_baseline_states_it(gab, orc):
         inner = face[1:-1, 1:-1]
         assert np.count_nonzero(np.abs(inner) > 1e-12) > 0.9 * inner.size     # developed values next to every face
         assert np.abs(inner).max() > 1e-7
-    plan.close()
+
+
+def test_fdtd_resident_launch_that_gives_up_fails_at_that_call():
+    """Diagnostic build (workgroup 0 of the resident kernel never publishes: GAB_FDTD_RES_ABLATE=2), in a child
+    process: the neighbours' bounded polls give up, the launch ENDS, THAT call's output is NaN in every sample,
+    gab_fdtd_status reports GAB_ERR_RUNTIME for it (once), and after a reset the
+    plan runs the step kernels and matches the oracle bit for bit (tools/fdtd_timeout_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gpuaudiobench_amd", "libgab_hip_ablate.so")
+    if not os.path.exists(lib):
+        pytest.skip("the diagnostic library is not built (GAB_BUILD_TAG=ablate GAB_ABLATE=1 python gpuaudiobench_amd/build.py)")
+    env = dict(os.environ, GAB_LIB_PATH=lib, GAB_FDTD_RES_ABLATE="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fdtd_timeout_check.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "matches the oracle bit for bit: ok" in r.stdout
 
 
 def test_fdtd_wide_slab_cut_developed_field(gab, orc):

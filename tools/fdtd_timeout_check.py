@@ -1,8 +1,9 @@
 """Diagnostic builds only (GAB_BUILD_TAG=ablate GAB_ABLATE=1 python gpuaudiobench_amd/build.py, then
 GAB_LIB_PATH=.../libgab_hip_ablate.so GAB_FDTD_RES_ABLATE=2 python tools/fdtd_timeout_check.py):
 workgroup 0 of the LDS-resident FDTD kernel never publishes its boundary pressures, so its neighbours'
-bounded polls must give up, the launch must END, the next gab_fdtd_process must report GAB_ERR_RUNTIME and the
-calls after that must run on the step kernels and match the oracle again."""
+bounded polls must give up, the launch must END, gab_fdtd_status must report GAB_ERR_RUNTIME for THAT call and the
+calls after that must run on the step kernels and match the oracle again; the failing call's output is NaN and
+gab_fdtd_status reports it at that call."""
 import os
 import sys
 import time
@@ -23,13 +24,19 @@ x = orc.Rand(1).bipolar(T * B)
 out = torch.zeros(T * B, device="cuda")
 t0 = time.time()
 plan.process(torch.from_numpy(x).cuda(), out, T, B, 0, B)
-torch.cuda.synchronize()
-print("launch with a silent workgroup ended after %.3f s" % (time.time() - t0))
 try:
-    plan.process(torch.from_numpy(x).cuda(), out, T, B, 0, B)
-    raise SystemExit("FAIL: the call after a timed-out launch did not report it")
+    plan.status()                                  # synchronises: the error belongs to THIS call
+    raise SystemExit("FAIL: gab_fdtd_status did not report the launch that gave up")
 except gab.GabError as e:
-    print("next call reported:", str(e)[:160])
+    assert e.code == -2, e.code
+    print("launch with a silent workgroup ended after %.3f s; gab_fdtd_status reported: %s" % (time.time() - t0, str(e)[:140]))
+got = out.cpu().numpy()
+assert np.isnan(got).all(), "the output of a launch that gave up must be NaN in every sample"
+print("that call's output is NaN in all %d samples" % got.size)
+try:
+    plan.status()
+except gab.GabError:
+    raise SystemExit("FAIL: the error was reported twice")
 assert not plan.resident()[0]
 plan.reset()
 P = orc.fdtd_params(n)
