@@ -51,7 +51,7 @@ CLOCK_WARM_STEPS = 500          # untimed, besides --warmup: ~0.2 s of the same 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 PARITY_CHANNELS = 16            # sampled per checked buffer
 PARITY_TOL = 1e-5               # of the stream's peak (north_star: 1e-5 relative for float DSP)
-TRAFFIC_SOURCE = "profiles/r03_conv_batch_pmc_means.json"
+TRAFFIC_SOURCE = "profiles/r04_conv_batch_pmc_means.json"
 
 
 def cpu_threads():
@@ -258,13 +258,16 @@ def main():
     if not args.no_side_legs:
         side = side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, args.batch_sizes)
 
-    traffic = None
+    traffic, pmc = None, {}
     pmc_file = os.path.join(ROOT, TRAFFIC_SOURCE)
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("hbm_traffic_bytes_per_launch")
+            pmc = json.load(open(pmc_file))
+            traffic = pmc.get("hbm_traffic_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic, pmc = None, {}
+    cnt = pmc.get("counters_mean_per_launch", {})
+    valu_share = (cnt["SQ_ACTIVE_INST_VALU"] / cnt["SQ_WAVE_CYCLES"]) if cnt.get("SQ_WAVE_CYCLES") and cnt.get("SQ_ACTIVE_INST_VALU") else None
 
     achieved = alg * NB / (launch_us * 1e-6) / 1e9
     result = {
@@ -307,6 +310,13 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "frac_wall": alg / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic,
+            # what the memory system really carried, against the same peak: `frac` prices the ALGORITHMIC bytes (SURVEY 8d:
+            # every tap and every history sample a 4096-tap FIR depends on), most of which this kernel keeps in LDS, registers
+            # and the Infinity Cache, so frac is a rate of useful work, not HBM utilisation
+            "hbm_frac_measured": (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic is not None and NB == BUFFERS_PER_STEP else None,
+            "bound_measured": ("barriers and latency of two resident waves per SIMD: VALU busy %.0f %% of wave-cycles, HBM-side traffic %.2f x "
+                               "algorithmic (counters of %s)" % (100 * valu_share, traffic / (alg * BUFFERS_PER_STEP), TRAFFIC_SOURCE))
+                              if traffic is not None and valu_share is not None else None,
             "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over the same "
                               "launch; not measured in this run)" if traffic is not None else None,
             "algorithmic_bytes_per_buffer": alg,

@@ -49,6 +49,16 @@ CASES = {
 }
 
 
+# Cases whose algorithmic bytes are dominated by what crosses the LINK in an iteration (the modal placeholder
+# uploads its 32 MiB parameter table every iteration and its kernel reads 32 records of it): the KERNEL is priced
+# against what the kernel itself reads and writes, the iteration against the link.
+KERNEL_BYTES = {"modal_placeholder": 32 * 8 * 4 + 32 * 512 * 4}
+# The LDS-resident FDTD kernel moves no field through HBM: its per-step floor is the longer of (a) VALU issue — the
+# counted instructions per SIMD and step x 4 cycles per wave64 instruction at the part's clock — and (b) the neighbour
+# hand-off's request-to-data round trip with every workgroup asking at once; profiles/r04_fdtd_bound.md holds both.
+FDTD_RESIDENT_FLOOR_US_PER_STEP = {"fdtd_128": None, "fdtd_52": None}     # filled from profiles/r04_fdtd_bound.json when present
+
+
 def run(case, iters=None):
     import gpuaudiobench_amd as gab
     name, cfg, n = CASES[case]
@@ -87,14 +97,23 @@ def collect(d, out_csv, out_md):
         ks = [r for r in csv.DictReader(open(sf)) if "gab::" in r["Name"]]
         total_avg = sum(float(r["AverageNs"]) * int(r["Calls"]) for r in ks)
         per_iter_ns = total_avg / max(1, meta["iterations"] + 5 + 1)      # timed + warm-up + the validation iteration
+        kbytes = KERNEL_BYTES.get(case, meta["algorithmic_bytes"])
+        floor = None
+        bf = os.path.join(ROOT, "profiles", "r04_fdtd_bound.json")
+        if case in FDTD_RESIDENT_FLOOR_US_PER_STEP and os.path.exists(bf):
+            floor = json.load(open(bf)).get(case, {}).get("floor_us_per_step")
         for r in ks:
             calls = int(r["Calls"])
             rows.append(dict(case=case, benchmark=meta["benchmark"], kernel=short(r["Name"]), calls=calls,
                              avg_us=float(r["AverageNs"]) / 1e3, min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3,
                              stddev_us=float(r["StdDev"]) / 1e3, kernels_us_per_iteration=per_iter_ns / 1e3,
-                             algorithmic_bytes=meta["algorithmic_bytes"],
-                             alg_GBps=meta["algorithmic_bytes"] / per_iter_ns if per_iter_ns > 0 else 0.0,
-                             frac_of_8TBps=meta["algorithmic_bytes"] / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0,
+                             algorithmic_bytes=kbytes,
+                             alg_GBps=kbytes / per_iter_ns if per_iter_ns > 0 else 0.0,
+                             # rooms resident in LDS: not an HBM figure at all — the fraction is of the kernel's own floor
+                             frac_of_8TBps=(kbytes / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0) if floor is None else None,
+                             bound=("hbm" if floor is None else "issue + neighbour hand-off, %.2f us per step" % floor),
+                             frac_of_bound=(None if floor is None else
+                                            floor * meta["config"].get("buffer_size", 512) * 3 / (per_iter_ns / 1e3)),
                              harness_device_median_us=meta["device_median_ms"] * 1e3, wall_median_us=meta["wall_median_ms"] * 1e3,
                              valid=meta["valid"], link_GBps_wall=meta.get("link_GBps_wall"),
                              link_GBps_device=meta.get("link_GBps_device")))
@@ -107,12 +126,17 @@ def collect(d, out_csv, out_md):
         f.write("Per-kernel, per-size device times (rocprofv3 --kernel-trace --stats, ONE pass per case; `kernels us/iter` = all\n"
                 "gab kernels of one harness iteration; frac = algorithmic bytes / that time / 8 TB/s; datacopy rows: link GB/s\n"
                 "= (in + out bytes) / wall median of H2D + kernel + D2H, against PCIe Gen5 x16 = 63 GB/s per direction).\n\n")
-        f.write("| case | kernel | calls | avg us | min us | kernels us/iter | alg. bytes | alg. GB/s | frac of 8 TB/s | link GB/s | valid |\n")
-        f.write("|---|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write("Rooms the FDTD3D kernel keeps resident in LDS cross no HBM roofline: their fraction is of the kernel's own per-step floor\n"
+                "(profiles/r04_fdtd_bound.md).  The modal placeholder's kernel is priced against the 66 560 B it reads and writes (its\n"
+                "iteration is the 32 MiB upload).\n\n")
+        f.write("| case | kernel | calls | avg us | min us | kernels us/iter | bytes priced | GB/s | bound | frac of bound | link GB/s | valid |\n")
+        f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for r in rows:
-            f.write("| %s | %s | %d | %.2f | %.2f | %.2f | %d | %.0f | %.3f | %s | %s |\n" % (
+            frac = r["frac_of_8TBps"] if r["frac_of_bound"] is None else r["frac_of_bound"]
+            f.write("| %s | %s | %d | %.2f | %.2f | %.2f | %d | %.0f | %s | %.3f | %s | %s |\n" % (
                 r["case"], r["kernel"], r["calls"], r["avg_us"], r["min_us"], r["kernels_us_per_iteration"], r["algorithmic_bytes"],
-                r["alg_GBps"], r["frac_of_8TBps"], "%.1f" % r["link_GBps_wall"] if r["link_GBps_wall"] else "", r["valid"]))
+                r["alg_GBps"], "8 TB/s HBM" if r["bound"] == "hbm" else r["bound"], frac,
+                "%.1f" % r["link_GBps_wall"] if r["link_GBps_wall"] else "", r["valid"]))
     print("wrote", out_csv, out_md, len(rows), "rows")
 
 
