@@ -425,6 +425,12 @@ __global__ __launch_bounds__(64) void dwg_naive_kernel(const WG* __restrict__ wg
     }
 }
 
+// writePos % L without the divide in the usual case (the harness never advances writePos: the reference's own defect,
+// SURVEY 2.3); the value is uniform over the workgroup either way
+__device__ __forceinline__ int wrap_once(int writePos, int L) {
+    return (unsigned)writePos < (unsigned)L ? writePos : writePos % L;
+}
+
 __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ wgs,
                                                        float* __restrict__ fwd, float* __restrict__ bwd,
                                                        const float* __restrict__ input,
@@ -443,8 +449,13 @@ __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ w
     // thread j owns the j-th cell the buffer visits: cell (writePos + j) % L, first touched by sample j
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= wg.length || s >= B) return;
-    const int p = (wg.writePos % wg.length + s) % wg.length;
-    const int bp = (p + wg.length / 2) % wg.length;
+    // (writePos % L + s) % L and (p + L/2) % L with both addends below L: one conditional subtraction each — the
+    // general modulo is ~40 VALU instructions by a run-time divisor, three of them per cell were most of this kernel
+    const int wp = wrap_once(wg.writePos, wg.length);
+    int p = wp + s;
+    if (p >= wg.length) p -= wg.length;
+    int bp = p + wg.length / 2;
+    if (bp >= wg.length) bp -= wg.length;
     float* F = fwd + (size_t)g * max_len + p;
     float* Bk = bwd + (size_t)g * max_len + bp;
     float f = *F, b = *Bk, mix;
@@ -456,6 +467,70 @@ __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ w
     }
     *F = f;
     *Bk = b;
+}
+
+// The same for banks of a thousand waveguides and more: a workgroup of the one-line kernel moves 4 KB and costs a dispatch,
+// and at 8 192 lines there are 16 384 of them (19.7 us for 67 MB).  Here a thread owns cell j of U consecutive lines: the
+// input is staged once per U lines, and the 2 U cell loads of a thread are all requested before the first is used.
+// Same operations per cell, same order: bit-identical.  Round 4, measured at 8 192 lines: 19.7 us (one line per workgroup,
+// three run-time modulos per cell) -> 16.9 us; the counters of that launch (tools/pmc_case.sh dwg_accel_8192): 32.7 MB
+// read + 30.3 MB written, the waves alive ~12 us of the launch's 17 = 5 TB/s while they run, VALU busy 14 % — the delay
+// lines' 2 KB pieces at DRAM rate plus a launch's ramp.  Four cells per thread as 16-byte pieces (a quarter of the
+// memory instructions): 17.7 us, not kept.
+template <int U>
+__global__ __launch_bounds__(256) void dwg_cells_multi_kernel(const WG* __restrict__ wgs,
+                                                             float* __restrict__ fwd, float* __restrict__ bwd,
+                                                             const float* __restrict__ input,
+                                                             float* __restrict__ ws, int2* __restrict__ hits, int n_wg, int B,
+                                                             int max_len, int* __restrict__ mix_count) {
+    __shared__ float xin[2048];
+    const int g0 = blockIdx.y * U;
+    if (mix_count && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < B; i += blockDim.x) mix_count[i] = 0;
+    const bool staged = B <= 2048;
+    if (staged) {
+        for (int i = threadIdx.x; i < B; i += blockDim.x) xin[i] = input[i];
+        __syncthreads();
+    }
+    const int s0 = blockIdx.x * blockDim.x + threadIdx.x;
+    WG wg[U];
+    float f[U], b[U];
+    float* F[U];
+    float* Bk[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int g = g0 + u;
+        live[u] = false;
+        if (g >= n_wg) continue;
+        wg[u] = wgs[g];
+        if (blockIdx.x == 0 && threadIdx.x == 0) dwg_publish_hits(wg[u], g, hits);
+        live[u] = s0 < wg[u].length && s0 < B;
+        int p = wrap_once(wg[u].writePos, wg[u].length) + s0;      // both below L (live threads): conditional subtractions
+        if (p >= wg[u].length) p -= wg[u].length;
+        int bp = p + wg[u].length / 2;
+        if (bp >= wg[u].length) bp -= wg[u].length;
+        F[u] = fwd + (size_t)g * max_len + p;
+        Bk[u] = bwd + (size_t)g * max_len + bp;
+        wg[u].pad = __int_as_float(p);                     // the cell, kept where the record has room
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (live[u]) { f[u] = *F[u]; b[u] = *Bk[u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        const int g = g0 + u;
+        const int p = __float_as_int(wg[u].pad);
+        const bool inject = (p == wg[u].inTap), tap = (p == wg[u].outTap);
+        float mix;
+        for (int s = s0; s < B; s += wg[u].length) {
+            float x = __fmul_rn(staged ? xin[s] : input[s], wg[u].gain);
+            dwg_step(f[u], b[u], x, inject, wg[u], mix);
+            if (tap) ws[(size_t)g * B + s] = mix;
+        }
+        *F[u] = f[u];
+        *Bk[u] = b[u];
+    }
 }
 
 // The ordered per-sample mix, sparse form.  A waveguide reaches its output tap at samples first + k * length:
@@ -646,9 +721,16 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                                                                          n_waveguides, bufsize, max_len, mix_count);
         } else {
             int cells = max_len < bufsize ? max_len : bufsize;   // a buffer visits min(L, B) cells of a line
-            dim3 grid((cells + 255) / 256, n_waveguides);
-            gab::dwg_cells_kernel<<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, n_waveguides,
-                                                       bufsize, max_len, mix_count);
+            constexpr int U = 8;
+            if (n_waveguides >= 1024) {                          // large banks: U lines per workgroup (see the kernel)
+                dim3 grid((cells + 255) / 256, (n_waveguides + U - 1) / U);
+                gab::dwg_cells_multi_kernel<U><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, n_waveguides,
+                                                                    bufsize, max_len, mix_count);
+            } else {
+                dim3 grid((cells + 255) / 256, n_waveguides);
+                gab::dwg_cells_kernel<<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, n_waveguides,
+                                                           bufsize, max_len, mix_count);
+            }
         }
         int rc = gab::launch_status("dwg kernel");
         if (rc) return rc;
