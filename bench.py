@@ -281,6 +281,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        "value_is": "throughput with %d buffers resident in HBM per launch (gab_conv_process_batch); the rate with ONE launch per "
+                    "buffer and the pinned-host round trip of one buffer are config.one_launch_per_buffer / config.round_trip" % NB,
         "dtype": "f32",
         "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: all ranks share device 0 over gloo",
         "config": {

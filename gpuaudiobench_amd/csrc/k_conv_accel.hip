@@ -39,6 +39,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -866,7 +867,7 @@ constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;   
 // after each barrier RELEASES them (slots 0-5) and at the period's start (6); slot = [block][wave][8].
 #define GAB_BSTAMP(i)                                                                                     \
     do {                                                                                                  \
-        if (GAB_SDBG(64) && nb == 32 && lane == 0)                                                        \
+        if (GAB_SDBG(64) && nb == (ENGINE ? 4000 : 32) && lane == 0)     /* the engine: once the clocks have settled */   \
             g_split_stamps[((size_t)blockIdx.x * 8 + w) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();    \
     } while (0)
 #else
@@ -874,10 +875,46 @@ constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;   
 #endif
 struct ArriveAtBarrier { __device__ __forceinline__ void operator()(int) const { __syncthreads(); } };
 
-__global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
+// ENGINE: the same launch fed through a doorbell (gab_conv_engine_*): it stays on the device and takes buffer nb from slot
+// nb % ring of an input ring when the doorbell word says it has been published, instead of n_buffers known at launch.
+//   doorbell   [pinned host memory] = buffers published so far, bit 31 = no more will come.  Only workgroup 0 reads it
+//              over the link — 256 workgroups asking the host every period cost 20-40 us per period, measured — and
+//              passes it on through a word in device memory (`relay`) that one lane of every workgroup (the first
+//              inverse wave's) asks for at the start of a period; the answer is needed at the period's end, so a
+//              producer that keeps a few buffers ahead never makes the engine wait; otherwise every wave of the
+//              workgroup parks at a barrier while that lane polls (bounded: then the engine stops with an error).
+//   period nb  runs when buffer nb + 1 is there too (its operands are requested one period ahead), or when the stop
+//              bit says buffer nb is the last; the output of buffer nb leaves one period later, as in a batch launch.
+//   progress   every inverse wave stores (write-through) how many buffers it has finished — one period late, when the
+//              rows' own stores have long drained, so nothing waits for it; one wave of workgroup 0 takes the minimum of
+//              all of them each period and writes it into `completed` (pinned host word).
+// The history ring is written every period (the last eight buffers are not known in advance) and the far role takes
+// blocks k-7 .. k-2 from it, as round 3's batch kernel did; everything else is the batch launch's code: same bits.
+struct ConvEngine {
+    const unsigned* doorbell;
+    unsigned* relay;              // device: the doorbell as workgroup 0 last saw it (zero at launch)
+    unsigned* progress;           // device: [2 x workgroups] buffers finished per inverse wave (zero at launch)
+    unsigned* completed;          // pinned host
+    unsigned* error;              // pinned host
+    int ring;                     // buffers in the input and output rings (>= 3)
+    int poll_every_period;        // 1; diagnostic builds may turn it off (the word is then read only when the engine stalls)
+};
+constexpr int kEnginePollLimit = 1 << 21;      // x ~1 us: about two seconds without the word moving
+
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+// experiments only (GAB_EXTRA_FLAGS=-DGAB_ENGV=bits, a build of its own): 1 no progress words / aggregator, 2 plain output
+// stores, 4 plain input loads, 8 history from the input ring as a batch launch takes it (needs a ring of >= 9 slots),
+// 32 the doorbell is read only when the engine stalls.  Compile-time: a run-time switch at every load perturbs what it measures.
+#ifndef GAB_ENGV
+#define GAB_ENGV 0
+#endif
+#define GAB_EABL(bit) ((GAB_ENGV & (bit)) != 0)
+
+template <bool ENGINE>
+__device__ __forceinline__ void conv_split_resident(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
-    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
-    __shared__ cf lds[kBatchLds];
+    const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0, int n_buffers,
+    const ConvEngine& eng, cf* __restrict__ lds, unsigned* __restrict__ s_door) {
     cf* const far_x = lds + 6 * kWaveImg;
     cf* const far_y = far_x + kLdsHalf;
     cf* const carry = far_y + kLdsHalf;                               // [pair of the duo][slot][512]
@@ -886,10 +923,67 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
     const size_t step = (size_t)T * kB;
     cf* const carry_g = sp.carry + (size_t)(2 * d) * kCarrySlots * kB;   // the duo's two rings are contiguous
     for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry[i] = carry_g[i];
+    constexpr int kPoller = 2 * 64;                                   // lane 0 of the first inverse wave
+    // the doorbell as this workgroup may read it: workgroup 0 asks the host and passes the answer on, the others ask the relay
+    auto read_door = [&]() -> unsigned {
+        if (blockIdx.x == 0) {
+            const unsigned v = __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(eng.relay, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        }
+        return __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if constexpr (ENGINE) {
+        if (tid == kPoller) s_door[0] = read_door();
+    }
     __syncthreads();
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    // How many buffers may be touched, asked by EVERY wave at the top of period nb (same answer in all of them: it is
+    // read from LDS, written before the previous period's closing barrier).  Batch launches: n_buffers.
+    auto gate = [&](int nb) -> int {
+        if constexpr (!ENGINE) {
+            return n_buffers;
+        } else {
+            for (;;) {
+                // (the same word in every lane: said so, or every test on it becomes an exec-masked region — the far
+                // role's request burst under a divergent branch took 2.4 instead of 1.4 us of its barrier interval)
+                const unsigned D = __builtin_amdgcn_readfirstlane(s_door[nb & 1]);
+                const int pub = (int)(D & 0x7fffffffu);
+                const bool stop = (D >> 31) != 0;
+                if (pub >= nb + 2 || (stop && pub >= nb + 1)) return pub;
+                if (stop) return nb;                                  // nothing more will come
+                __syncthreads();                                      // every wave has read the word
+                if (tid == kPoller) {
+                    unsigned v = D;
+                    int tries = 0;
+                    for (;;) {
+                        v = read_door();
+                        const int p2 = (int)(v & 0x7fffffffu);
+                        if (p2 >= nb + 2 || (v >> 31)) break;
+                        if (++tries > kEnginePollLimit) {             // the producer is gone: stop here, say so
+                            __hip_atomic_store(eng.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            v = 0x80000000u | (unsigned)(p2 < nb ? p2 : nb);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(20);
+                    }
+                    s_door[nb & 1] = v;
+                }
+                __syncthreads();
+            }
+        }
+    };
+    // buffer nb lives in slot nb % ring of the engine's rings (a batch launch: buffer nb itself); callers walk the slots
+    // with next_slot() instead of dividing
+    auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
+    auto next_slot = [&](int slot) -> int { return (ENGINE && slot + 1 == eng.ring) ? 0 : slot + 1; };
+    // the engine's input ring is rewritten while the launch runs: its loads must not be answered by a line this CU kept
+    auto ld = [](const float* p) -> float {
+        if constexpr (ENGINE) return GAB_EABL(4) ? *p : __builtin_nontemporal_load(p);
+        else return *p;
+    };
 
     if (w >= 4) {
         // ---- far waves: F of the pair whose turn it is (window = blocks k-7 .. k; the two newest straight from
@@ -905,18 +999,37 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         // Blocks that lie inside the launch come from the input buffers (block k-j = buffer nb-j), older ones
         // from the history ring as the previous launch left it: the ring is neither read nor written in the
         // steady state of a launch (the forward waves refresh it over the launch's last eight buffers).
-        auto load_window = [&](int nb, cf (&z)[16], float4 (&c)[16]) {
+        // FIRST (a compile-time tag): the launch's first window, whose block k-1 is still the history ring's.  (As a
+        // run-time test on nb the engine's k-1 loads became conditional loads: a register merge behind them, i.e. a
+        // wait for the whole request burst in the middle of the far chain — 2.3 instead of 1.4 us for that interval.)
+        auto load_window = [&](auto first_tag, int nb, int slot, int slot_before, cf (&z)[16], float4 (&c)[16]) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const int head = (head0 + nb) & (kSlots - 1);
             const int q = 2 * d + (head & 1);
             const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
             const size_t ca = (size_t)(2 * q) * kB, cb_ = ca + kB;
-            const float* const cur = in + nb * step;
-            z[14] = mk(cur[ca + ft], cur[cb_ + ft]);
-            z[15] = mk(cur[ca + ft + kThreads], cur[cb_ + ft + kThreads]);
-            if (nb >= kSlots - 1) {                                   // the whole window lies inside the launch
+            const float* const cur = in_slot(slot);
+            z[14] = mk(ld(cur + ca + ft), ld(cur + cb_ + ft));
+            z[15] = mk(ld(cur + ca + ft + kThreads), ld(cur + cb_ + ft + kThreads));
+            if constexpr (ENGINE && !GAB_EABL(8)) {                   // k-1 from the input ring, the rest from the history ring
+                if constexpr (!FIRST) {
+                    const float* const prv = in_slot(slot_before);
+                    z[12] = mk(ld(prv + ca + ft), ld(prv + cb_ + ft));
+                    z[13] = mk(ld(prv + ca + ft + kThreads), ld(prv + cb_ + ft + kThreads));
+                } else {
+                    const int s = ((head + kSlots - 1) & (kSlots - 1)) * kB;
+                    z[12] = hp[s + ft];
+                    z[13] = hp[s + kThreads + ft];
+                }
+#pragma unroll
+                for (int r = 0; r < 12; ++r)
+                    z[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
+            } else if (nb >= kSlots - 1) {                            // the whole window lies inside the launch
 #pragma unroll
                 for (int bl = 0; bl < 7; ++bl) {
-                    const float* const src = cur - (size_t)(7 - bl) * step;
+                    int sb = slot - (7 - bl);                         // (engine experiments: the ring wraps)
+                    if (ENGINE && sb < 0) sb += eng.ring;
+                    const float* const src = in_slot(sb);
                     z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
                     z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
                 }
@@ -924,7 +1037,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
 #pragma unroll
                 for (int bl = 0; bl < 7; ++bl) {                      // block k-7+bl = buffer nb-7+bl (uniform branch)
                     if (nb - 7 + bl >= 0) {
-                        const float* const src = cur - (size_t)(7 - bl) * step;
+                        const float* const src = in_slot(slot - (7 - bl));       // nb < 7: no wrap yet
                         z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
                         z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
                     } else {
@@ -938,8 +1051,12 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         };
         cf zb[16], zn[16];
         float4 cb[16];
-        load_window(0, zb, cb);
-        for (int nb = 0; nb < n_buffers; ++nb) {
+        int avail = gate(0);
+        if (avail > 0) load_window(std::true_type{}, 0, 0, 0, zb, cb);
+        int slot = 0;                                                 // of buffer nb
+        for (int nb = 0;; ++nb, slot = next_slot(slot)) {
+            if (nb > 0) avail = gate(nb);
+            if (nb >= avail) break;
 #ifdef GAB_ABLATE
             if (GAB_SDBG(4)) {                                        // diagnostic builds: far role idle
                 for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
@@ -958,7 +1075,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             GAB_BSTAMP(2);
             spectral_product<kNB, 16>(zb, zn, cb, ft);
             __builtin_amdgcn_sched_barrier(0);
-            if (nb + 1 < n_buffers) load_window(nb + 1, zn, cb);      // flies under the inverse transform
+            if (nb + 1 < avail) load_window(std::false_type{}, nb + 1, next_slot(slot), slot, zn, cb);   // flies under the inverse transform
             __builtin_amdgcn_sched_barrier(0);
 #ifdef GAB_ABLATE
             FBi::template run<typename FB::Twiddles, 4>(zb, far_y, far_x, twb, ft, true, [&](int p) { GAB_BSTAMP(3 + p); });
@@ -988,17 +1105,21 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         WF::load_twiddles(t, tw, lane);
         const float4* const pa = pmA + (size_t)q * kBinsA;
         const float4* const pa2 = sp.pmA2 + (size_t)q * kBinsA;
-        const float* const xa0 = in + (size_t)(2 * q) * kB;           // channel a of buffer 0; channel b is kB further
+        const size_t xoff = (size_t)(2 * q) * kB;                     // channel a of a buffer; channel b is kB further
         cf z[16], prev[8], nxt[8];
         float4 c[16];
+        int avail = gate(0);
         {   // prologue: the spectrum of the ring's blocks [k-2 | k-1] into the image
             const int s1 = ((head0 + kSlots - 1) & (kSlots - 1)) * kB, s2 = ((head0 + kSlots - 2) & (kSlots - 1)) * kB;
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
 #pragma unroll
             for (int j = 0; j < 8; ++j) prev[j] = hp[s1 + lane + 64 * j];
+            if (avail > 0) {
+                const float* const x0 = in_slot(0) + xoff;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) nxt[j] = mk(xa0[lane + 64 * j], xa0[kB + lane + 64 * j]);
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(ld(x0 + lane + 64 * j), ld(x0 + kB + lane + 64 * j));
+            }
             load_spectra<kNA, 16>(c, pa2, lane);
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[8 + j] = prev[j];
@@ -1007,7 +1128,10 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
             __builtin_amdgcn_wave_barrier();
         }
-        for (int nb = 0; nb < n_buffers; ++nb) {
+        int slot = 0;                                                 // of buffer nb
+        for (int nb = 0;; ++nb, slot = next_slot(slot)) {
+            if (nb > 0) avail = gate(nb);
+            if (nb >= avail) break;
 #ifdef GAB_ABLATE
             if (GAB_SDBG(1)) {                                        // diagnostic builds: near role idle
                 for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
@@ -1039,18 +1163,18 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             __syncthreads();                                          // barrier 1
 #pragma unroll
             for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
-            if (nb + kSlots >= n_buffers) {                           // the ring only has to hold the launch's LAST eight blocks
+            if ((ENGINE && !GAB_EABL(8)) || nb + kSlots >= n_buffers) {   // the ring only has to hold the launch's LAST eight blocks
 #pragma unroll
                 for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
-            if (nb + 1 < n_buffers) {                                 // the next buffer's block: needed a period from now
+            if (nb + 1 < avail) {                                     // the next buffer's block: needed a period from now
                 int lo = lane;
                 asm volatile("" : "+v"(lo));
-                const float* const xa = xa0 + (nb + 1) * step + lo;
+                const float* const xa = in_slot(next_slot(slot)) + xoff + lo;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) nxt[j] = mk(xa[64 * j], xa[kB + 64 * j]);
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(ld(xa + 64 * j), ld(xa + kB + 64 * j));
             }
 #ifdef GAB_ABLATE
             WF::run(z, img, t, lane, [&](int i) { GAB_BSTAMP(1 + i); __syncthreads(); });
@@ -1094,18 +1218,65 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
         using WFi = fft::WaveFFT1024<true>;
         WFi::Lean t;
         WFi::load_twiddles(t, tw, lane);
-        for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // first period: nothing to turn yet
-        for (int nb = 1; nb <= n_buffers; ++nb) {
+        int oslot = 0;                                                // of buffer nb - 1, from period 1 on
+        for (int nb = 0;; ++nb) {
+            const int avail = gate(nb);
+            const bool more = nb < avail;                             // the other roles work on buffer nb in this period
+            unsigned door_next = s_door[nb & 1];                      // (no per-period poll: the word as last seen)
+            u4 prog_a = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, prog_b = prog_a;
+            if constexpr (ENGINE) {
+                if (nb >= 2 && !GAB_EABL(1)) {
+                    // this wave's rows of buffer nb - 2 were stored a period ago: drained by now, so the wait is free,
+                    // and the count of finished buffers can go out (write-through, nobody waits for it)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)(nb - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == kPoller && eng.poll_every_period)          // asked now, needed at the period's end
+                    door_next = blockIdx.x == 0 ? __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) {     // the aggregator: every wave's count, 8 per lane
+                    const auto srd = __builtin_amdgcn_make_buffer_rsrc(eng.progress, 0, (int)(8u * gridDim.x), 0x00020000);
+                    prog_a = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane, 0, 16);          // sc1; beyond the end: zeros dropped below
+                    prog_b = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane + 16u, 0, 16);
+                }
+            }
+            auto close_period = [&]() {                               // before the closing barrier
+                if constexpr (ENGINE) {
+                    if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) {
+                        const unsigned words = 2u * gridDim.x;        // lanes beyond the array read zeros: mask them out
+                        auto pick = [&](unsigned v, unsigned idx) { return idx < words ? v : 0xffffffffu; };
+                        unsigned m = min(min(min(pick(prog_a[0], 8u * lane), pick(prog_a[1], 8u * lane + 1)), min(pick(prog_a[2], 8u * lane + 2), pick(prog_a[3], 8u * lane + 3))),
+                                         min(min(pick(prog_b[0], 8u * lane + 4), pick(prog_b[1], 8u * lane + 5)), min(pick(prog_b[2], 8u * lane + 6), pick(prog_b[3], 8u * lane + 7))));
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+                        if (lane == 0) __hip_atomic_store(eng.completed, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    if (tid == kPoller) {
+                        s_door[(nb + 1) & 1] = door_next;
+                        if (blockIdx.x == 0 && eng.poll_every_period)
+                            __hip_atomic_store(eng.relay, door_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            };
+            if (nb == 0) {                                            // first period: nothing to turn yet
+                for (int i = 0; i < kBatchBarriers - 1; ++i) __syncthreads();
+                close_period();
+                __syncthreads();
+                if (!more) break;
+                continue;
+            }
 #ifdef GAB_ABLATE
             if (GAB_SDBG(1)) {                                        // diagnostic builds: near role idle
                 for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
+                if (!more) break;
                 continue;
             }
 #endif
             // One piece per barrier interval: hand-over read | pass 0 | pass 1 | pass 2 + far share | swap | stores
             const int b = nb - 1;                                     // the buffer whose spectrum was handed over last period
             const int head = (head0 + b) & (kSlots - 1);
-            float* const outb = out + b * step;
+            float* const outb = out + (size_t)(ENGINE ? oslot : b) * step;
+            oslot = next_slot(oslot);
             cf z[16], y[8], park[8];
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];    // the forward wave writes the next one in interval 6
@@ -1135,27 +1306,53 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
             __syncthreads();                                          // barrier 5: the swapped halves are in LDS
             {
                 float* const o0 = outb + 4 * (size_t)d;
+                auto put = [&](float* dst, float a, float b2, float c2, float d2) {
+                    if (ENGINE && !GAB_EABL(2)) {                     // write-through: in memory before `completed` says so
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        const f4v val = {a, b2, c2, d2};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = make_float4(a, b2, c2, d2);
+                    }
+                };
                 if (pr == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const cf theirs = other[lane + 64 * j];
-                        *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * j)) = make_float4(y[j].x, y[j].y, theirs.x, theirs.y);
+                        put(o0 + (size_t)T * (lane + 64 * j), y[j].x, y[j].y, theirs.x, theirs.y);
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const cf theirs = other[lane + 64 * j];
-                        *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * (4 + j))) = make_float4(theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                        put(o0 + (size_t)T * (lane + 64 * (4 + j)), theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
                     }
                 }
             }
             GAB_BSTAMP(5);
+            close_period();
             __syncthreads();                                          // barrier 6 closes the period
             GAB_BSTAMP(6);
+            if (!more) break;
         }
     }
     // every wave is past the last closing barrier: the duo's carry ring goes back to memory
     for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry_g[i] = carry[i];
+}
+
+__global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
+    __shared__ cf lds[kBatchLds];
+    conv_split_resident<false>(in, out, hist, pmA, sp, tw, T, head0, n_buffers, ConvEngine{}, lds, nullptr);
+}
+
+__global__ __launch_bounds__(kBatchThreads, 2) void conv_split_engine_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, ConvEngine eng) {
+    __shared__ cf lds[kBatchLds];
+    __shared__ unsigned door[2];
+    conv_split_resident<true>(in, out, hist, pmA, sp, tw, T, head0, 0, eng, lds, door);
 }
 
 // IR bank -> (P, M) spectra of a near (512 taps from offA) and a far (taps from offB) partition.
@@ -1484,6 +1681,16 @@ struct gab_conv_plan {
     unsigned rt_epoch = 0;
     int rt_groups = 0, rt_pairs_per_group = 0;
     const void* rt_checked_out = nullptr;
+    // gab_conv_engine_* (split cut): one resident launch fed through a doorbell
+    float* eng_in = nullptr;            // fine-grained device memory: [ring][T*B], the producer writes it while the launch runs
+    float* eng_out = nullptr;           // [ring][B*T]
+    unsigned* eng_done = nullptr;       // device: buffers finished per inverse wave [2 x workgroups]
+    unsigned* eng_words = nullptr;      // pinned host: [0] doorbell, [16] completed, [32] error
+    int eng_ring = 0;
+    bool eng_running = false;
+    unsigned eng_published = 0;
+    unsigned eng_seen_completed = 0;
+    hipStream_t eng_stream = nullptr;
     // uniform partitions (conv_uniform_kernel): other power-of-two buffer sizes / longer responses
     bool uniform = false;
     int uJ = 0, uS = 0, ring_len = 0;
@@ -1599,6 +1806,14 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->rt_park) (void)hipFree(p->rt_park);
     if (p->rt_counters) (void)hipFree(p->rt_counters);
     if (p->rt_words) (void)hipHostFree(p->rt_words);
+    if (p->eng_running) {                                            // never leave a resident launch behind
+        if (p->eng_words) __atomic_store_n(&p->eng_words[0], p->eng_published | 0x80000000u, __ATOMIC_RELEASE);
+        (void)hipDeviceSynchronize();
+    }
+    if (p->eng_in) (void)hipFree(p->eng_in);
+    if (p->eng_out) (void)hipFree(p->eng_out);
+    if (p->eng_done) (void)hipFree(p->eng_done);
+    if (p->eng_words) (void)hipHostFree(p->eng_words);
     if (p->rt_copy_ev) (void)hipEventDestroy(p->rt_copy_ev);
     if (p->rt_copy_stream) (void)hipStreamDestroy(p->rt_copy_stream);
     delete p;
@@ -1836,6 +2051,131 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         if (*error != 0) {
             *error = 0;
             gab::set_last_error("gab_conv_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
+            return GAB_ERR_RUNTIME;
+        }
+        return GAB_OK;
+    });
+}
+
+// ---- the doorbell-fed engine ------------------------------------------------------------------------------------------
+int gab_conv_engine_rings(gab_conv_plan* p, int ring_buffers, float** d_in_ring, float** d_out_ring) {
+    return gab::guarded([&]() -> int {
+        if (!p || !d_in_ring || !d_out_ring) return gab::bad_arg("gab_conv_engine_rings: null argument");
+        if (!(p->fused && p->split)) return gab::bad_arg("gab_conv_engine_rings: the engine runs the split cut (512-sample buffers, 1025..4096 taps, channels divisible by 4)");
+        if (p->eng_running) return gab::bad_arg("gab_conv_engine_rings: the plan's engine is running");
+        if (ring_buffers < 3 || ring_buffers > 4096) return gab::bad_arg("gab_conv_engine_rings: ring_buffers must be 3..4096");
+        const size_t n = (size_t)p->tracks * p->bufsize;
+        if (p->eng_ring != ring_buffers) {
+            if (p->eng_in) { (void)hipFree(p->eng_in); p->eng_in = nullptr; }
+            if (p->eng_out) { (void)hipFree(p->eng_out); p->eng_out = nullptr; }
+            p->eng_ring = 0;
+            // fine-grained: what a copy or another agent writes there is seen by the running launch
+            unsigned flags = hipDeviceMallocFinegrained;
+#ifdef GAB_ABLATE
+            if (getenv("GAB_ENGINE_COARSE")) flags = hipDeviceMallocDefault;       // diagnostic builds: ordinary device memory
+#endif
+            GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->eng_in), n * 4 * ring_buffers, flags));
+            GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->eng_out), n * 4 * ring_buffers, flags));
+            p->eng_ring = ring_buffers;
+        }
+        *d_in_ring = p->eng_in;
+        *d_out_ring = p->eng_out;
+        return GAB_OK;
+    });
+}
+
+int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring, float** d_out_ring, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!p || !d_in_ring || !d_out_ring) return gab::bad_arg("gab_conv_engine_start: null argument");
+        if (!p->ir_set) return gab::bad_arg("gab_conv_engine_start: gab_conv_set_ir has not been called");
+        if (p->eng_running) return gab::bad_arg("gab_conv_engine_start: the plan's engine is already running");
+        if (int rc = gab_conv_engine_rings(p, ring_buffers, d_in_ring, d_out_ring)) return rc;
+        hipStream_t s = gab::as_stream(stream);
+        const size_t prog_words = 2 * (size_t)(p->tracks / 4) + 32;        // + the relay word on a line of its own
+        if (!p->eng_done) GAB_HIP_CHECK(hipMalloc(&p->eng_done, prog_words * sizeof(unsigned)));
+        if (!p->eng_words) {
+            GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->eng_words), 64 * sizeof(unsigned), hipHostMallocDefault));
+        }
+        for (int i = 0; i < 64; ++i) p->eng_words[i] = 0;
+        p->order_after_reset(s);
+        GAB_HIP_CHECK(hipMemsetAsync(p->eng_done, 0, prog_words * sizeof(unsigned), s));
+        gab::ConvSplit sp{p->pmA2, p->pmF, p->carry GAB_SPLIT_DEBUG_ARG};
+        int poll = (GAB_ENGV & 32) ? 0 : 1;
+#ifdef GAB_ABLATE
+        if (getenv("GAB_ENGINE_NOPOLL")) poll = 0;      // diagnostic builds: the doorbell is read only when the engine stalls
+
+#endif
+        gab::ConvEngine eng{p->eng_words, p->eng_done + prog_words - 1, p->eng_done, p->eng_words + 16, p->eng_words + 32, ring_buffers, poll};
+        gab::conv_split_engine_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
+            p->eng_in, p->eng_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, eng);
+        int rc = gab::launch_status("conv_split_engine_kernel");
+        if (rc) return rc;
+        p->eng_running = true;
+        p->eng_published = 0;
+        p->eng_seen_completed = 0;
+        p->eng_stream = s;
+        p->fresh = false;
+        *d_in_ring = p->eng_in;
+        *d_out_ring = p->eng_out;
+        return GAB_OK;
+    });
+}
+
+int gab_conv_engine_publish(gab_conv_plan* p, int n_more) {
+    if (!p || !p->eng_running) return gab::bad_arg("gab_conv_engine_publish: no running engine");
+    if (n_more < 0) return gab::bad_arg("gab_conv_engine_publish: negative count");
+    p->eng_published += (unsigned)n_more;
+    __atomic_store_n(&p->eng_words[0], p->eng_published, __ATOMIC_RELEASE);       // the doorbell: buffers published so far
+    return GAB_OK;
+}
+
+int gab_conv_engine_completed(gab_conv_plan* p, int* completed) {
+    if (!p || !completed || !p->eng_words) return gab::bad_arg("gab_conv_engine_completed: no engine");
+    const unsigned c = __atomic_load_n(&p->eng_words[16], __ATOMIC_ACQUIRE);      // two writers may cross: keep the maximum seen
+    if ((int)(c - p->eng_seen_completed) > 0) p->eng_seen_completed = c;
+    *completed = (int)p->eng_seen_completed;
+    return GAB_OK;
+}
+
+int gab_conv_engine_feed(gab_conv_plan* p, int n_buffers, int ahead) {
+    return gab::guarded([&]() -> int {
+        if (!p || !p->eng_running) return gab::bad_arg("gab_conv_engine_feed: no running engine");
+        // a buffer is reported back once FIVE later ones are published (asked for a period early, delivered a period late,
+        // its count taken a period after that and passed on by workgroup 0): fewer than six in flight and nothing moves
+        if (n_buffers < 0 || ahead < 6 || ahead >= p->eng_ring)
+            return gab::bad_arg("gab_conv_engine_feed: n_buffers >= 0 and 6 <= ahead < ring_buffers (a buffer is reported back once five later ones are published)");
+        const unsigned first = p->eng_published, last = first + (unsigned)n_buffers;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        int done = 0;
+        // one buffer per ring of the doorbell, never more than `ahead` buffers in front of what has come back
+        while (p->eng_published < last) {
+            gab_conv_engine_completed(p, &done);
+            if ((int)(p->eng_published - (unsigned)done) < ahead) gab_conv_engine_publish(p, 1);
+            if ((++spins & 0xfffffu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0 + 1e-4 * n_buffers) {
+                gab::set_last_error("gab_conv_engine_feed: the engine stopped consuming");
+                return GAB_ERR_RUNTIME;
+            }
+            if (p->eng_words[32]) break;
+        }
+        if (p->eng_words[32]) {
+            gab::set_last_error("gab_conv_engine_feed: the engine gave up waiting for the doorbell");
+            return GAB_ERR_RUNTIME;
+        }
+        return GAB_OK;
+    });
+}
+
+int gab_conv_engine_stop(gab_conv_plan* p) {
+    return gab::guarded([&]() -> int {
+        if (!p || !p->eng_running) return gab::bad_arg("gab_conv_engine_stop: no running engine");
+        __atomic_store_n(&p->eng_words[0], p->eng_published | 0x80000000u, __ATOMIC_RELEASE);
+        GAB_HIP_CHECK(hipStreamSynchronize(p->eng_stream));
+        p->eng_running = false;
+        p->eng_seen_completed = p->eng_published;            // the launch has ended: everything published is finished
+        p->head = (p->head + (int)(p->eng_published & 7u)) & (gab::kSlots - 1);
+        if (p->eng_words[32]) {
+            gab::set_last_error("gab_conv_engine_stop: the engine had given up waiting for the doorbell (about two seconds without a buffer or the stop)");
             return GAB_ERR_RUNTIME;
         }
         return GAB_OK;

@@ -39,6 +39,15 @@ def _acc(t, dtype=torch.float32):
     return _dev(t, dtype)
 
 
+def _view(ptr, rows, cols):
+    """A torch tensor over library-owned device memory (no ownership: keep the plan alive)."""
+    class _Mem:
+        pass
+    m = _Mem()
+    m.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(m, device="cuda")
+
+
 def device_count():
     n = C.c_int(0)
     check(lib.gab_device_count(C.byref(n)))
@@ -192,6 +201,37 @@ class ConvPlan:
     @staticmethod
     def launch_round_trip(args):
         check(lib.gab_conv_round_trip(*args))
+
+    # ---- the doorbell-fed resident engine (gab_conv_engine_*) ----
+    def engine_rings(self, ring_buffers):
+        """The engine's rings without starting it (to fill resident input before the launch takes the device)."""
+        a, b = C.c_void_p(), C.c_void_p()
+        check(lib.gab_conv_engine_rings(self._h, ring_buffers, C.byref(a), C.byref(b)))
+        n = self.tracks * self.bufsize
+        return _view(a.value, ring_buffers, n), _view(b.value, ring_buffers, n)
+
+    def engine_start(self, ring_buffers, stream=None):
+        """Launches the resident engine; returns (in_ring, out_ring) as device tensors [ring][T*B] / [ring][B*T]
+        viewing the plan's rings."""
+        a, b = C.c_void_p(), C.c_void_p()
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        check(lib.gab_conv_engine_start(self._h, ring_buffers, C.byref(a), C.byref(b), st))
+        n = self.tracks * self.bufsize
+        return _view(a.value, ring_buffers, n), _view(b.value, ring_buffers, n)
+
+    def engine_publish(self, n_more=1):
+        check(lib.gab_conv_engine_publish(self._h, n_more))
+
+    def engine_completed(self):
+        v = C.c_int(0)
+        check(lib.gab_conv_engine_completed(self._h, C.byref(v)))
+        return v.value
+
+    def engine_feed(self, n_buffers, ahead=4):
+        check(lib.gab_conv_engine_feed(self._h, n_buffers, ahead))
+
+    def engine_stop(self):
+        check(lib.gab_conv_engine_stop(self._h))
 
     def process_batch(self, x, n_buffers, out=None):
         """n_buffers consecutive buffers ([n][T*B] in, [n][B*T] out) in one launch."""

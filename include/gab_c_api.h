@@ -122,7 +122,11 @@ typedef struct {
 
 #define GAB_DWG_NAIVE 0   /* DWG1DNaiveKernel (cuda/bench_dwg.cu:10-59)       */
 #define GAB_DWG_ACCEL 1   /* DWG1DAccelKernel (cuda/bench_dwg.cu:61-141)      */
-/* Workspace the ordered (atomic-free) output reduction needs, in bytes.      */
+/* Workspace the ordered (atomic-free) output reduction needs, in bytes: the tap contributions [n][bufsize], then
+ * (since round 3) where every line reaches its tap, the per-sample hit counters and the hit lists.  gab_dwg takes no
+ * size argument and writes ALL of these on every call: d_workspace MUST hold at least what this function returns
+ * for the same (n_waveguides, bufsize) — a buffer sized n*bufsize floats by an older reading of this header is too
+ * small and would be written past its end.                                                                */
 size_t gab_dwg_workspace_bytes(int n_waveguides, int bufsize);
 /* Updates the two delay-line banks (n_wg x max_len) in place and writes the
  * mono mix d_out[bufsize], summed over waveguides in index order.            */
@@ -201,6 +205,32 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  Blocking; one call at a time
  * per plan.  GAB_ERR_RUNTIME if the input never arrived (the output of that call is then invalid).       */
 int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
+/* ---- a resident engine fed through a doorbell (additive; split-cut plans) -----------------------------------------
+ * For a caller whose buffers ARRIVE one at a time but who can keep a couple in flight: ONE launch (the batch launch's
+ * kernel) stays on the device and convolves buffer k as soon as the host — or anything that can write the slot — has
+ * published it, so no kernel boundary separates buffers (conv_split_kernel: 8.9 us per buffer; the engine: the batch
+ * rate).  Same state, same bits as gab_conv_process.
+ *   rings     allocates (once per ring size) input / output rings of ring_buffers slots ([slot][T*B] track-major in,
+ *             [slot][B*T] sample-major out; fine-grained device memory: COPY ENGINES may write and read them while the
+ *             launch runs — kernels cannot: at 1024 channels the engine holds every compute unit until it stops);
+ *   start     the same rings, and launches on `stream`, which the launch occupies until stop;
+ *   publish   after buffer k has been written to slot k % ring_buffers: the doorbell count goes up by n_more;
+ *   completed buffers whose output is complete in its slot.  The engine asks for a buffer one period before it uses it,
+ *             delivers one period after, counts a period later and passes the doorbell on inside the device, so buffer
+ *             k is reported once k + 5 is published (or the stop rung): keep at least six in flight, and a ring
+ *             of at least seven slots.  A producer reuses slot k % ring only when completed > k - ring;
+ *   feed      a host loop for resident rings: rings the doorbell n_buffers times, one buffer each, never more than
+ *             `ahead` (6 <= ahead < ring_buffers) in front of `completed`;
+ *   stop      rings the stop bit, waits for the launch to end (every published buffer is finished), carries the
+ *             history on for the next gab_conv_process / batch / engine.
+ * The device is the engine's while it runs (256 workgroups at 1024 channels): other kernels queue behind it.  If the
+ * doorbell does not move for about two seconds the launch ends by itself and stop / feed return GAB_ERR_RUNTIME.      */
+int gab_conv_engine_rings(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring);
+int gab_conv_engine_start(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring, gab_stream_t stream);
+int gab_conv_engine_publish(gab_conv_plan* plan, int n_more);
+int gab_conv_engine_completed(gab_conv_plan* plan, int* completed);
+int gab_conv_engine_feed(gab_conv_plan* plan, int n_buffers, int ahead);
+int gab_conv_engine_stop(gab_conv_plan* plan);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
                          size_t* history_bytes);

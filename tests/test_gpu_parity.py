@@ -436,6 +436,79 @@ def test_conv_accel_round_trip_other_plans_and_arguments(gab, orc):
         b.close()
 
 
+def test_conv_accel_engine_fed_through_the_doorbell_same_bits(gab, orc):
+    """gab_conv_engine_*: one resident launch that takes buffers as they are published.  An eight-slot ring refilled by
+    copies WHILE the launch runs (so the launch must see fresh data in a slot it has read before), one buffer per ring
+    of the doorbell, slots reused only after their buffer came back; every output bit for bit what one
+    gab_conv_process launch per buffer gives, the history carried on into ordinary launches after the stop."""
+    import torch
+    T, B, L, R, N = 64, 512, 4096, 8, 30
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    xs = [orc.noise(T * B, seed=200 + i) for i in range(N + 2)]     # (a buffer comes back once five more are published: the ring holds eight)
+    want = [host(a.process(dev(x), mode=gab.CONV_STREAMING)) for x in xs]
+    # two ordinary launches first: the engine starts from a history that is not empty
+    for k in range(2):
+        assert np.array_equal(bits(host(b.process(dev(xs[k]), mode=gab.CONV_STREAMING))), bits(want[k]))
+    side = torch.cuda.Stream()                       # the engine owns its stream until stop
+    in_ring, out_ring = b.engine_start(R, stream=side)
+    cur = torch.cuda.current_stream()
+    got = {}
+
+    def collect():
+        done = b.engine_completed()
+        for k in range(len(got), done):
+            got[k] = out_ring[k % R].cpu().numpy().copy()          # a copy on the default stream: the slot is complete
+        return done
+
+    import time
+    for k in range(N):
+        t0 = time.time()
+        while k - collect() >= R:                    # slot k % R still holds an output nobody has taken / an input in use
+            assert time.time() - t0 < 20, "the engine stopped returning buffers (completed %d of %d published)" % (len(got), k)
+        in_ring[k % R].copy_(torch.from_numpy(xs[2 + k]).pin_memory(), non_blocking=True)   # a copy ENGINE's work
+        cur.synchronize()                            # the slot is written before the doorbell rings
+        b.engine_publish(1)
+    b.engine_stop()                                  # everything published is finished when this returns
+    assert collect() == N
+    for k in range(N):
+        assert np.array_equal(bits(got[k]), bits(want[2 + k])), "buffer %d" % k
+    with pytest.raises(gab.GabError):
+        b.engine_publish(1)                          # no running engine
+    a.close()
+    b.close()
+
+
+def test_conv_accel_engine_feed_matches_batch_launches_and_carries_history(gab, orc):
+    """gab_conv_engine_feed on resident rings (what bench.py times): 3 x 16 buffers, one per ring of the doorbell with
+    at most eight in flight, leave in the output ring what three batch launches of 16 leave; ordinary launches after
+    the stop continue the same stream."""
+    import torch
+    T, B, L, R = 1024, 512, 4096, 16
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    x = torch.cat([dev(orc.noise(T * B, seed=300 + i)) for i in range(R)])
+    side = torch.cuda.Stream()
+    in_ring, out_ring = b.engine_rings(R)            # filled BEFORE the launch: at this size the engine holds every CU,
+    in_ring.copy_(x.view(R, T * B))                  # and a copy KERNEL would queue behind it (copy engines would not)
+    torch.cuda.synchronize()
+    b.engine_start(R, stream=side)
+    b.engine_feed(3 * R, ahead=8)
+    b.engine_stop()
+    for _ in range(3):
+        y = a.process_batch(x, R)
+    torch.cuda.synchronize()
+    assert torch.equal(out_ring.reshape(-1).view(torch.int32), y.view(torch.int32))
+    x2 = dev(orc.noise(T * B, seed=7))
+    assert torch.equal(a.process(x2).view(torch.int32), b.process(x2).view(torch.int32))
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
                                       (4, 512, 1100, 37), (2048, 512, 4096, 3), (12, 512, 4096, 1), (36, 512, 3000, 2),
                                       (8192, 512, 4096, 2),      # C5's channel count: 2048 workgroups, eight rounds of the device
