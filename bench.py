@@ -426,6 +426,44 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
         "us_per_buffer": one_us, "buffers_per_sec": 1e6 / one_us, "alg_GBps": alg / one_us / 1e3,
         "frac": alg / one_us / 1e3 / HBM_PEAK_GBS, "launches": 4000}
 
+    # ---- the same buffers ARRIVING one at a time at a resident launch (gab_conv_engine_*): the host rings the doorbell once
+    # per buffer and keeps at most `ahead` in flight; the ring is the resident batch.  HIP events on the engine's own
+    # stream around the whole launch; the output ring checked bit for bit against batch launches over the same buffers.
+    ahead, passes = 16, 63
+    ref = gab.ConvPlan(T, B, L, scheme="split")
+    ref.set_ir(ir_dev)
+    yref = torch.empty_like(xb)
+    eplan = gab.ConvPlan(T, B, L, scheme="split")
+    eplan.set_ir(ir_dev)
+    in_ring, out_ring = eplan.engine_rings(NB)
+    in_ring.copy_(xb.view(NB, T * B))
+    warm = plan.prepare_batch(xb, NB, yref)           # the clocks settle over ~40 ms of sustained load: the same warm-up as `value`
+    for _ in range(300):
+        plan.launch_batch(warm)
+    torch.cuda.synchronize()
+    yref = None
+    for _ in range(passes):                           # (the warm-up used the buffer: the reference again)
+        yref = ref.process_batch(xb, NB, out=yref)
+    ref.close()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record(side)
+    eplan.engine_start(NB, stream=side)
+    eplan.engine_feed(passes * NB, ahead=ahead)
+    eplan.engine_stop()
+    g1.record(side)
+    side.synchronize()
+    eng_us = g0.elapsed_time(g1) * 1e3 / (passes * NB)
+    res["one_buffer_per_doorbell"] = {
+        "entry": "gab_conv_engine_start / _feed / _stop: one resident launch (conv_split_engine_kernel), the host publishes ONE "
+                 "buffer per ring of the doorbell and keeps at most %d in flight" % ahead,
+        "us_per_buffer": eng_us, "buffers_per_sec": 1e6 / eng_us, "alg_GBps": alg / eng_us / 1e3,
+        "frac": alg / eng_us / 1e3 / HBM_PEAK_GBS, "buffers": passes * NB, "ahead": ahead,
+        "bit_identical_to_batch_launches": bool(torch.equal(out_ring.reshape(-1).view(torch.int32), yref.view(torch.int32)))}
+    eplan.close()
+    plan.reset()
+
     # ---- batch size: how the per-launch cost (first window, drain, boundary) amortises
     sizes = {}
     for nb in ((8, 16, 32) if batch_sizes else ()):

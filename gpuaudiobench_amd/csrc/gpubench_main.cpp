@@ -39,7 +39,8 @@ void printHelp() {
     printf("  --fdtdSteps [n]     FDTD3D: leapfrog steps per iteration (3 per sample: sets the buffer to ceil(n/3) samples)\n");
     printf("  --fdtdForm [f]      FDTD3D: auto (the room resident in LDS where it fits, one launch per buffer; default) |\n");
     printf("                      step (one launch per step: for a device shared with other work)\n");
-    printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless\n");
+    printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless | roundtrip (stream, with the\n");
+    printf("                      iteration's upload, kernel and download overlapped in one call: gab_conv_round_trip)\n");
     printf("  --convBatch [n]     Conv1D_accel: an iteration is ONE launch over n HBM-resident buffers (throughput mode,\n");
     printf("                      no per-iteration copies); default: one buffer per iteration with its copies\n");
     printf("  --gpus [n]          Run on n devices, one host thread each: gain, GainStats, IIRFilter, FFT1D, RndMemRead, Conv1D\n");
@@ -288,7 +289,8 @@ int main(int argc, char** argv) {
         }
         else if (strcmp(argv[i], "--convMode") == 0) {
             if (!need("--convMode")) return 1;
-            CONV_STREAMING = strcmp(argv[++i], "stateless") == 0 ? 0 : 1;
+            const char* m = argv[++i];
+            CONV_STREAMING = strcmp(m, "stateless") == 0 ? 0 : (strcmp(m, "roundtrip") == 0 ? 2 : 1);
         } else if (strcmp(argv[i], "--modalMode") == 0) {
             if (!need("--modalMode")) return 1;
             MODAL_REAL = strcmp(argv[++i], "bank") == 0 ? 1 : 0;

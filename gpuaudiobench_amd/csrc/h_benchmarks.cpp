@@ -574,7 +574,8 @@ Conv1DAccelBenchmark::Conv1DAccelBenchmark(int ir_length, size_t buffer_size, si
       mode_(mode),
       track_offset_(track_offset),
       total_tracks_(total_tracks ? total_tracks : track_count),
-      batch_(CONV_BATCH > 1 ? CONV_BATCH : 0) {
+      batch_(CONV_BATCH > 1 ? CONV_BATCH : 0),
+      round_trip_(CONV_STREAMING == 2) {
     if (ir_length <= 0) throw std::invalid_argument("Conv1DAccelBenchmark: ir_length must be > 0");
     say("Conv1DAccelBenchmark: IR length = %d, FFT size = %d\n", ir_length_, fft_size_);
     ir_buffer_size = track_count * ir_length;
@@ -599,6 +600,12 @@ void Conv1DAccelBenchmark::setupBenchmark() {
     cpu_reference = allocateHostBuffer<float>(getTotalElements(), "conv1d_accel cpu reference");
     checkGab(gab_conv_create(&plan_, static_cast<int>(getTrackCount()), static_cast<int>(getBufferSize()),
                              ir_length_), "gab_conv_create");
+    if (round_trip_) {
+        if (mode_ != Mode::STREAMING || batch_ > 1)
+            throw std::invalid_argument("Conv1DAccelBenchmark: --convMode roundtrip is the streaming mode, one buffer per iteration");
+        // the overlapped form runs the classic cut, whose long partition does not need the new block
+        if (gab_conv_set_scheme(plan_, GAB_CONV_SCHEME_CLASSIC) != GAB_OK) (void)gab_last_error();   // shapes without a choice: no matter
+    }
     BenchmarkUtils::generateConvAccelImpulseResponses(h_ir_buf, ir_length_, track_offset_, getTrackCount(),
                                                       total_tracks_);
     if (d_shared_ir_) {
@@ -655,6 +662,13 @@ void Conv1DAccelBenchmark::performBenchmarkIteration() {
         HIP_CHECK(hipMemcpyAsync(getHostOutput(), d_batch_out_, getTotalElements() * sizeof(float),
                                  hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
+        return;
+    }
+    if (round_trip_) {
+        // --convMode roundtrip: the iteration's three stages as ONE call in which the upload, the kernel and the
+        // download overlap (gab_conv_round_trip; the reference runs them one after the other, cuda/bench_base.cu:30-42).
+        // Nothing separable remains for a device timer: the iteration's wall time is the figure.
+        checkGab(gab_conv_round_trip(plan_, getHostInput(), getHostOutput(), stream_), "gab_conv_round_trip");
         return;
     }
     transferToDevice();

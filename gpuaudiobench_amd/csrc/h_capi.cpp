@@ -125,7 +125,7 @@ int gab_bench_create(gab_bench** out, const char* name, const gab_bench_config* 
         std::lock_guard<std::mutex> lock(g_globals_mu);
         FS = c.fs; BUFSIZE = c.buffer_size; NTRACKS = c.n_tracks; NRUNS = c.n_runs;
         IR_LENGTH = c.ir_length; FDTD_GRID = c.fdtd_grid;
-        CONV_STREAMING = (c.conv_mode == GAB_CONV_STREAMING) ? 1 : 0;
+        CONV_STREAMING = (c.conv_mode == GAB_CONV_STREAMING) ? 1 : (c.conv_mode == GAB_CONV_STREAMING_HOST_IO ? 2 : 0);
         GAB_QUIET = c.quiet != 0;
         MODAL_REAL = c.modal_mode != 0;
         CONV_BATCH = c.conv_batch;

@@ -274,6 +274,7 @@ private:
     int overlap_size_;   // L-1 (:53) — the history this build actually carries
     Mode mode_;
     size_t track_offset_, total_tracks_;
+    bool round_trip_ = false;         // --convMode roundtrip: every iteration is one gab_conv_round_trip call
     float* h_ir_buf = nullptr;
     float* d_ir_buf = nullptr;
     float* cpu_reference = nullptr;

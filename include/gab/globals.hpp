@@ -19,7 +19,7 @@ extern bool JSON_OUTPUT;         // --json
 // Additions of the MI355X build (unreachable from the reference CLI):
 extern int IR_LENGTH;            // --irLength     (<=0: each benchmark's DEFAULT_IR_LEN)
 extern int FDTD_GRID;            // --fdtdGrid     (<=0: 52, the reference's 50+2)
-extern int CONV_STREAMING;       // --convMode stream|stateless (default stream)
+extern int CONV_STREAMING;       // --convMode stateless (0) | stream (1, default) | roundtrip (2: stream, overlapped iteration)
 extern int MODAL_REAL;           // --modalMode placeholder|bank (default placeholder = the CUDA port)
 extern bool GAB_QUIET;           // suppress progress chatter (library use)
 

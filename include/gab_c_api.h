@@ -370,7 +370,8 @@ typedef struct {
     int    fs, buffer_size, n_tracks, n_runs;       /* cuda/globals.cu:4-7     */
     int    ir_length;       /* <=0: the benchmark's DEFAULT_IR_LEN             */
     int    fdtd_grid;       /* <=0: 52 (bench_fdtd3d.cuh:36-38)                */
-    int    conv_mode;       /* GAB_CONV_*                                      */
+    int    conv_mode;       /* GAB_CONV_STATELESS | GAB_CONV_STREAMING | 2: streaming with every
+                               iteration ONE gab_conv_round_trip call (--convMode roundtrip)   */
     int    quiet;           /* suppress the reference's progress printf        */
     int    modal_mode;      /* ModalFilterBank: 0 the CUDA port's placeholder
                                (bench_modal.cu:15-36), 1 the real bank (Metal port) */

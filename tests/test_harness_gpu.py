@@ -285,3 +285,25 @@ def test_driver_gpus_says_which_partition_ran(name):
         assert part.startswith("contiguous channel shards")
         assert ("halo" in part) == (name == "Conv1D") and ("pool" in part) == (name == "RndMemRead")
     assert j["multi_gpu"]["ranks"][0]["valid"] is True and j["multi_gpu"]["ranks"][0]["tracks"] == 16
+
+
+def test_conv_accel_round_trip_mode_through_the_harness_and_the_driver(gab):
+    """--convMode roundtrip / conv_mode = 2: every iteration of the reference-shaped loop is ONE gab_conv_round_trip
+    call (upload, kernel and download overlapped) instead of copy, kernel, copy: validates against the same golden
+    and the iteration's wall time drops (C3: ~63 us against ~112 us; asserted loosely: below 0.8 of it)."""
+    cfg = dict(n_tracks=1024, ir_length=4096)
+    lat = {}
+    for mode in (1, 2):
+        b = gab.Benchmark("Conv1D_accel", conv_mode=mode, **cfg)
+        b.setup()
+        r = b.run(iterations=200, warmup=20)
+        v, text = b.validate()
+        assert v.status == 0 and v.max_error <= 1e-5, text
+        lat[mode] = r.median_ms
+        b.close()
+    assert lat[2] < 0.8 * lat[1], lat
+    r = run_driver("--benchmark", "Conv1D_accel", "--irLength", "4096", "--nTracks", "1024", "--convMode", "roundtrip",
+                   "--nRuns", "100", "--json", "--cpu-threads", "0")
+    assert r.returncode == 0, r.stdout[-2000:]
+    j = _json_of(r.stdout)
+    assert j["validation"]["passed"] is True and j["statistics"]["p50_ms"] < 0.09
