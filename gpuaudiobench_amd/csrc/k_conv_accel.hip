@@ -904,7 +904,7 @@ constexpr int kEnginePollLimit = 1 << 21;      // x ~1 us: about two seconds wit
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // experiments only (GAB_EXTRA_FLAGS=-DGAB_ENGV=bits, a build of its own): 1 no progress words / aggregator, 2 plain output
 // stores, 4 plain input loads, 8 history from the input ring as a batch launch takes it (needs a ring of >= 9 slots),
-// 32 the doorbell is read only when the engine stalls.  Compile-time: a run-time switch at every load perturbs what it measures.
+// 32 the doorbell is read only when the engine stalls, 64 rings in ordinary device memory.  Compile-time: a run-time switch at every load perturbs what it measures.
 #ifndef GAB_ENGV
 #define GAB_ENGV 0
 #endif
@@ -2070,10 +2070,7 @@ int gab_conv_engine_rings(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
             if (p->eng_out) { (void)hipFree(p->eng_out); p->eng_out = nullptr; }
             p->eng_ring = 0;
             // fine-grained: what a copy or another agent writes there is seen by the running launch
-            unsigned flags = hipDeviceMallocFinegrained;
-#ifdef GAB_ABLATE
-            if (getenv("GAB_ENGINE_COARSE")) flags = hipDeviceMallocDefault;       // diagnostic builds: ordinary device memory
-#endif
+            unsigned flags = (GAB_ENGV & 64) ? hipDeviceMallocDefault : hipDeviceMallocFinegrained;   // (experiments: ordinary device memory)
             GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->eng_in), n * 4 * ring_buffers, flags));
             GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->eng_out), n * 4 * ring_buffers, flags));
             p->eng_ring = ring_buffers;
