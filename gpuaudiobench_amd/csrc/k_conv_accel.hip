@@ -1823,6 +1823,7 @@ int gab_conv_destroy(gab_conv_plan* p) {
 int gab_conv_set_ir(gab_conv_plan* p, const float* d_ir, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p || !d_ir) return gab::bad_arg("gab_conv_set_ir: null argument");
+        if (p->eng_running) return gab::bad_arg("gab_conv_set_ir: the plan's engine is running (gab_conv_engine_stop first)");
         hipStream_t s = gab::as_stream(stream);
         if (p->uniform) {
             for (int j = 0; j < p->uJ; ++j)
@@ -1870,6 +1871,7 @@ int gab_conv_get_scheme(const gab_conv_plan* p, int* scheme) {
 int gab_conv_reset(gab_conv_plan* p, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_conv_reset: null plan");
+        if (p->eng_running) return gab::bad_arg("gab_conv_reset: the plan's engine is running (gab_conv_engine_stop first)");
         hipStream_t s = gab::as_stream(stream);
         {
             // launches still in flight on other streams read the rings: the memsets go behind them
@@ -1903,6 +1905,7 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
     return gab::guarded([&]() -> int {
         if (!p || !d_in || !d_out) return gab::bad_arg("gab_conv_process: null argument");
         if (!p->ir_set) return gab::bad_arg("gab_conv_process: gab_conv_set_ir has not been called");
+        if (p->eng_running) return gab::bad_arg("gab_conv_process: the plan's engine is running and owns its history (gab_conv_engine_stop first)");
         if (mode != GAB_CONV_STATELESS && mode != GAB_CONV_STREAMING && mode != GAB_CONV_STREAMING_HOST_IO)
             return gab::bad_arg("gab_conv_process: unknown mode");
         hipStream_t s = gab::as_stream(stream);
@@ -2002,6 +2005,7 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
     return gab::guarded([&]() -> int {
         if (!p || !h_in || !h_out) return gab::bad_arg("gab_conv_round_trip: null argument");
         if (!p->ir_set) return gab::bad_arg("gab_conv_round_trip: gab_conv_set_ir has not been called");
+        if (p->eng_running) return gab::bad_arg("gab_conv_round_trip: the plan's engine is running and owns its history (gab_conv_engine_stop first)");
         hipStream_t s = gab::as_stream(stream);
         if (!(p->fused && p->tail && !p->split && (p->tracks % 4) == 0)) {
             // every other plan: the kernel moves the buffers over the link itself (h_in must then be pinned too)
@@ -2184,6 +2188,7 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
     return gab::guarded([&]() -> int {
         if (!p || !d_in || !d_out) return gab::bad_arg("gab_conv_process_batch: null argument");
         if (!p->ir_set) return gab::bad_arg("gab_conv_process_batch: gab_conv_set_ir has not been called");
+        if (p->eng_running) return gab::bad_arg("gab_conv_process_batch: the plan's engine is running and owns its history (gab_conv_engine_stop first)");
         if (n_buffers <= 0) return gab::bad_arg("gab_conv_process_batch: n_buffers must be > 0");
         hipStream_t s = gab::as_stream(stream);
         if (p->fused && p->split) {

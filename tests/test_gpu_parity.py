@@ -375,6 +375,10 @@ def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, 
             worst, peak = max(worst, float(np.abs(yb - ref).max())), max(peak, float(np.abs(ref).max()))
     if T <= 64:
         assert worst / peak <= 1e-5
+    # a pageable input: every group comes by the engine copy (a pinned one lets the kernel read the first group itself)
+    x = orc.noise(T * B, seed=8)
+    ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+    assert np.array_equal(bits(ya), bits(b.round_trip(torch.from_numpy(x.copy()), h_out).numpy()))
     # the staging buffer is re-armed after every buffer: the same input twice in a row is two buffers, not one
     x = orc.noise(T * B, seed=7)
     h_in.copy_(torch.from_numpy(x))
@@ -471,6 +475,9 @@ def test_conv_accel_engine_fed_through_the_doorbell_same_bits(gab, orc):
         in_ring[k % R].copy_(torch.from_numpy(xs[2 + k]).pin_memory(), non_blocking=True)   # a copy ENGINE's work
         cur.synchronize()                            # the slot is written before the doorbell rings
         b.engine_publish(1)
+    for call in (lambda: b.process(dev(xs[0])), b.reset, lambda: b.process_batch(dev(np.concatenate(xs[:2])), 2)):
+        with pytest.raises(gab.GabError):            # the running engine owns the plan's history
+            call()
     b.engine_stop()                                  # everything published is finished when this returns
     assert collect() == N
     for k in range(N):
