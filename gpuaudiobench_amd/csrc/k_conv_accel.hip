@@ -2007,8 +2007,20 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         if (!p->ir_set) return gab::bad_arg("gab_conv_round_trip: gab_conv_set_ir has not been called");
         if (p->eng_running) return gab::bad_arg("gab_conv_round_trip: the plan's engine is running and owns its history (gab_conv_engine_stop first)");
         hipStream_t s = gab::as_stream(stream);
+        auto mapped = [](const void* ptr) {               // may a kernel touch it?  (pinned host or device memory)
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, ptr) != hipSuccess || at.devicePointer == nullptr) {
+                (void)hipGetLastError();
+                return false;
+            }
+            return true;
+        };
         if (!(p->fused && p->tail && !p->split && (p->tracks % 4) == 0)) {
-            // every other plan: the kernel moves the buffers over the link itself (h_in must then be pinned too)
+            // every other plan: the kernel moves the buffers over the link itself — both must be mapped into the device
+            // (a kernel that dereferences pageable host memory faults)
+            if (!mapped(h_in) || !mapped(h_out))
+                return gab::bad_arg("gab_conv_round_trip: on this plan (not the classic cut at 512-sample buffers) the kernel reads h_in and "
+                                    "writes h_out itself: both must be pinned host memory (hipHostMalloc) or device memory");
             int rc = gab_conv_process(p, h_in, h_out, GAB_CONV_STREAMING_HOST_IO, stream);
             if (rc) return rc;
             GAB_HIP_CHECK(hipStreamSynchronize(s));
@@ -2016,11 +2028,8 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         }
         if (!p->rt_stage) gab_conv_round_trip_init(p);
         if (p->rt_checked_out != h_out) {              // the kernel writes h_out itself: it must be mapped into the device
-            hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, h_out) != hipSuccess || at.devicePointer == nullptr) {
-                (void)hipGetLastError();
+            if (!mapped(h_out))
                 return gab::bad_arg("gab_conv_round_trip: h_out must be pinned host memory (hipHostMalloc) or device memory");
-            }
             p->rt_checked_out = h_out;
         }
         p->order_after_reset(s);

@@ -436,6 +436,8 @@ def test_conv_accel_round_trip_other_plans_and_arguments(gab, orc):
             assert np.array_equal(bits(ya), bits(yb))
         with pytest.raises(TypeError):
             b.round_trip(torch.from_numpy(x).pin_memory(), torch.empty(T * B))       # pageable output
+        with pytest.raises(gab.GabError):
+            b.round_trip(torch.from_numpy(x.copy()), h_out)       # these plans' kernels read the input themselves: pageable is refused, not dereferenced
         a.close()
         b.close()
 
