@@ -1075,8 +1075,14 @@ __device__ __forceinline__ void conv_split_resident(
             GAB_BSTAMP(2);
             spectral_product<kNB, 16>(zb, zn, cb, ft);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef GAB_ABLATE
+            if (!GAB_SDBG(512)) { keep_alive(zb[0]); keep_alive(zb[15]); GAB_BSTAMP(7); }      // slot 7: the product is done
+#endif
             if (nb + 1 < avail) load_window(std::false_type{}, nb + 1, next_slot(slot), slot, zn, cb);   // flies under the inverse transform
             __builtin_amdgcn_sched_barrier(0);
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(512)) GAB_BSTAMP(7);                                                   // or: the request burst has been issued
+#endif
 #ifdef GAB_ABLATE
             FBi::template run<typename FB::Twiddles, 4>(zb, far_y, far_x, twb, ft, true, [&](int p) { GAB_BSTAMP(3 + p); });
 #else

@@ -3,7 +3,7 @@
 of the six barriers (and the release of the last); far waves (4-7) stamp each barrier's RELEASE (and the period's
 start).  Prints, over all 256 workgroups, the median interval lengths and how long each near stage waits."""
 import ctypes, os, sys
-os.environ["GAB_CONV_SPLIT_DEBUG"] = "64"
+os.environ.setdefault("GAB_CONV_SPLIT_DEBUG", "64")
 sys.path.insert(0, ".")
 import numpy as np, torch
 import gpuaudiobench_amd as gab
@@ -24,6 +24,7 @@ rel = far[:, :6] - start[:, None]
 print("far view: barrier release times after the period's start (us), median over workgroups:")
 print("   " + "  ".join("b%d %.2f" % (i + 1, np.median(rel[:, i])) for i in range(6)))
 iv = np.diff(np.concatenate([np.zeros((256, 1)), rel], axis=1), axis=1)
+print("   far wave, slot 7 (%s) after the period's start: %.2f us" % ("request burst issued" if int(os.environ.get("GAB_CONV_SPLIT_DEBUG", "64")) & 512 else "spectral product done", np.median(far[:, 7] - start)))
 print("   interval lengths: " + "  ".join("%.2f" % np.median(iv[:, i]) for i in range(6)) + "   period %.2f" % np.median(rel[:, 5]))
 for wv, name in ((0, "forward (pair 0)"), (1, "forward (pair 1)"), (2, "inverse (pair 0)"), (3, "inverse (pair 1)")):
     arr = st[:, wv, :6] - start[:, None]

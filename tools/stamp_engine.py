@@ -1,7 +1,7 @@
 """Diagnostic build only (GAB_LIB_PATH=.../libgab_hip_ablate.so): the barrier timeline of tools/stamp_batch.py for the
 doorbell-fed ENGINE launch (period 4000 of a run whose buffers were all published before the launch looked: ~25 ms in, clocks settled)."""
 import ctypes, os, sys
-os.environ["GAB_CONV_SPLIT_DEBUG"] = "64"
+os.environ.setdefault("GAB_CONV_SPLIT_DEBUG", "64")
 sys.path.insert(0, ".")
 import numpy as np, torch
 import gpuaudiobench_amd as gab
@@ -25,6 +25,7 @@ rel = far[:, :6] - start[:, None]
 print("ENGINE, far view: barrier release times after the period's start (us), median over workgroups:")
 print("   " + "  ".join("b%d %.2f" % (i + 1, np.median(rel[:, i])) for i in range(6)))
 iv = np.diff(np.concatenate([np.zeros((256, 1)), rel], axis=1), axis=1)
+print("   far wave, slot 7 (%s) after the period's start: %.2f us" % ("request burst issued" if int(os.environ.get("GAB_CONV_SPLIT_DEBUG", "64")) & 512 else "spectral product done", np.median(far[:, 7] - start)))
 print("   interval lengths: " + "  ".join("%.2f" % np.median(iv[:, i]) for i in range(6)) + "   period %.2f" % np.median(rel[:, 5]))
 for wv, name in ((0, "forward (pair 0)"), (1, "forward (pair 1)"), (2, "inverse (pair 0)"), (3, "inverse (pair 1)")):
     arr = st[:, wv, :6] - start[:, None]
