@@ -2062,7 +2062,10 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) { *landed = epoch; told = true; }
             if ((++spins & 1023u) == 0 &&
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
-                gab::set_last_error("gab_conv_round_trip: the launch did not complete within 4 s");
+                // the launch bounds its own waits (about a second each): let it end before the caller may free the buffers
+                (void)hipStreamSynchronize(s);
+                (void)hipStreamSynchronize(p->rt_copy_stream);
+                gab::set_last_error("gab_conv_round_trip: the launch did not report completion within 4 s; the output of this call is invalid");
                 return GAB_ERR_RUNTIME;
             }
         }
