@@ -125,6 +125,7 @@ PROTOTYPES = {
     "gab_fdtd_emit": (_I, [_P, _P, _I, _I, _P]),
     "gab_fdtd_strip": (_I, [_P, C.POINTER(_P), C.POINTER(_I)]),
     "gab_generate_noise": (_I, [_P, _Z, C.c_uint]),
+    "gab_glibc_rand": (_I, [C.c_uint, C.c_ulonglong, _P, _Z]),
     "gab_shard_range": (_I, [_I, _I, _Z, C.POINTER(_Z), C.POINTER(_Z)]),
     "gab_shard_range_aligned": (_I, [_I, _I, _Z, _Z, C.POINTER(_Z), C.POINTER(_Z)]),
     "gab_shard_granule": (_Z, [C.c_char_p]),

@@ -48,6 +48,16 @@ int gab_generate_conv_accel_ir(float* h_ir, int ir_len, size_t off, size_t n, si
     });
 }
 
+int gab_glibc_rand(unsigned seed, unsigned long long skip, int* out, size_t n) {
+    return gab::guarded([&]() -> int {
+        if (!out && n) return gab::bad_arg("gab_glibc_rand: null pointer");
+        BenchmarkUtils::GlibcRand rng(seed);
+        rng.discard(skip);
+        for (size_t i = 0; i < n; ++i) out[i] = rng.next();
+        return GAB_OK;
+    });
+}
+
 int gab_calculate_statistics(const float* lat, size_t n, gab_statistics* out) {
     return gab::guarded([&]() -> int {
         if (!out || (!lat && n)) return gab::bad_arg("gab_calculate_statistics: null pointer");

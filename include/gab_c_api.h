@@ -334,6 +334,11 @@ int gab_generate_conv1d_ir(float* h_ir, int ir_len, size_t track_offset,
 int gab_generate_conv_accel_ir(float* h_ir, int ir_len, size_t track_offset,
                                size_t n_tracks, size_t total_tracks);
 
+/* The stream glibc's srand(seed) + rand() gives (random_r.c TYPE_3), from its `skip`-th value on, as the harness draws it
+ * for FFT1D's input and RndMemRead's pool and playheads (private generators: no other rand() user or thread moves
+ * them, and a channel shard enters them at its first track).  Host arithmetic; additive.                          */
+int gab_glibc_rand(unsigned seed, unsigned long long skip, int* out, size_t n);
+
 /* Channel shards of a multi-GPU job (additive; BASELINE configs[4]): the contiguous range
  * [*lo, *hi) of `rank` out of `world`, the remainder going to the low ranks.  Host arithmetic.  */
 int gab_shard_range(int rank, int world, size_t total_tracks, size_t* lo, size_t* hi);

@@ -243,3 +243,20 @@ def test_conv1d_shards_carry_their_halo_rows_and_shared_outputs_stay_replicas():
     b = {"o": (np.arange(6, 9, dtype=np.float32), 0, 3), "s": (np.array([9, 8], np.float32), 1, 2)}
     j = sharding.join_results([a, b])
     assert j["o"].tolist() == list(range(9)) and j["s"].tolist() == [0, 1, 9, 2, 3, 8]
+
+
+def test_private_rand_streams_are_the_platforms_and_can_be_entered_anywhere():
+    """BenchmarkUtils::GlibcRand (the harness draws FFT1D's input and RndMemRead's pool / playheads from it) gives the
+    very stream the platform's srand(seed) + rand() gives, and `skip` enters it where a channel shard's first track starts."""
+    import ctypes as C
+    from gpuaudiobench_amd import _capi
+    libc = C.CDLL(None)
+    for seed in (1, 42, 12345):
+        libc.srand(seed)
+        ref = np.array([libc.rand() for _ in range(3000)], np.int32)
+        got = np.empty(3000, np.int32)
+        assert _capi.lib.gab_glibc_rand(seed, 0, got.ctypes.data_as(C.c_void_p), got.size) == 0
+        assert np.array_equal(got, ref)
+        part = np.empty(500, np.int32)
+        assert _capi.lib.gab_glibc_rand(seed, 1234, part.ctypes.data_as(C.c_void_p), part.size) == 0
+        assert np.array_equal(part, ref[1234:1734])
