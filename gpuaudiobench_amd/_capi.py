@@ -45,7 +45,7 @@ class FdtdParams(C.Structure):
 
 class BenchConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
-        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet", "modal_mode", "conv_batch", "fdtd_form")]
+        "fs", "buffer_size", "n_tracks", "n_runs", "ir_length", "fdtd_grid", "conv_mode", "quiet", "modal_mode", "conv_batch", "fdtd_form", "datacopy_mode")]
 
 
 class BenchResult(C.Structure):
@@ -79,6 +79,9 @@ PROTOTYPES = {
     "gab_gain": (_I, [_P, _P, _Z, _F, _P]),
     "gab_gainstats": (_I, [_P, _P, _P, _I, _I, _F, _P]),
     "gab_datatransfer": (_I, [_P, _P, _I, _I, _P]),
+    "gab_link_plan_create": (_I, [_I, C.POINTER(_P)]),
+    "gab_link_plan_destroy": (None, [_P]),
+    "gab_datatransfer_round_trip": (_I, [_P, _P, _P, _I, _I, _P]),
     "gab_iir": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_iir_sequential": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_conv1d": (_I, [_P, _P, _P, _I, _I, _I, _P]),

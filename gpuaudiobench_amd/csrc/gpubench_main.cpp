@@ -39,6 +39,8 @@ void printHelp() {
     printf("  --fdtdSteps [n]     FDTD3D: leapfrog steps per iteration (3 per sample: sets the buffer to ceil(n/3) samples)\n");
     printf("  --fdtdForm [f]      FDTD3D: auto (the room resident in LDS where it fits, one launch per buffer; default) |\n");
     printf("                      step (one launch per step: for a device shared with other work)\n");
+    printf("  --datacopyMode [m]  datacopy*: overlap (ONE engine upload beside a kernel that writes the pinned output as the input\n");
+    printf("                      lands: both link directions at once; default) | sequential (H2D -> kernel -> D2H, as the reference)\n");
     printf("  --convMode [m]      Conv1D_accel: stream (carried history, default) | stateless | roundtrip (stream, with the\n");
     printf("                      iteration's upload, kernel and download overlapped in one call: gab_conv_round_trip)\n");
     printf("  --convBatch [n]     Conv1D_accel: an iteration is ONE launch over n HBM-resident buffers (throughput mode,\n");
@@ -268,6 +270,13 @@ int main(int argc, char** argv) {
             if (strcmp(m, "auto") == 0) FDTD_FORM = 0;
             else if (strcmp(m, "step") == 0) FDTD_FORM = 1;
             else { printf("Error: --fdtdForm takes auto or step\n"); return 1; }
+        }
+        else if (strcmp(argv[i], "--datacopyMode") == 0) {
+            if (!need("--datacopyMode")) return 1;
+            const char* m = argv[++i];
+            if (strcmp(m, "overlap") == 0) DATACOPY_SEQUENTIAL = 0;
+            else if (strcmp(m, "sequential") == 0) DATACOPY_SEQUENTIAL = 1;
+            else { printf("Error: --datacopyMode takes overlap or sequential\n"); return 1; }
         }
         else if (strcmp(argv[i], "--gpus") == 0) {
             if (!need("--gpus")) return 1;

@@ -224,6 +224,7 @@ DataTransferBenchmark::DataTransferBenchmark(float input_ratio, float output_rat
     : DataTransferBenchmark(Config{input_ratio, output_ratio, name}) {}
 
 DataTransferBenchmark::~DataTransferBenchmark() {
+    if (link_plan_) gab_link_plan_destroy(link_plan_);
     freeHostBuffers({h_input_var, h_output_var, cpu_reference});
     freeDeviceBuffers({d_input_var, d_output_var});
 }
@@ -241,6 +242,7 @@ void DataTransferBenchmark::setupBenchmark() {
     d_input_var = allocateDeviceBuffer<float>(input_size, n + " device input buffer");
     d_output_var = allocateDeviceBuffer<float>(output_size, n + " device output buffer");
     std::memset(h_output_var, 0, output_size_bytes);
+    if (!DATACOPY_SEQUENTIAL) checkGab(gab_link_plan_create(input_size, &link_plan_), "gab_link_plan_create");
     cpu_reference = allocateHostBuffer<float>(output_size, n + " cpu reference");
     for (int i = 0; i < input_size; ++i)
         h_input_var[i] = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
@@ -257,13 +259,24 @@ bool DataTransferBenchmark::cpuGoldenWhole() {
 
 void DataTransferBenchmark::runKernel() { performBenchmarkIteration(); }
 
-// pinned hipHostMalloc buffers + hipMemcpyAsync: H2D, kernel and D2H are queued
-// back to back on one stream; the host blocks once, at the end.
+// pinned hipHostMalloc buffers + hipMemcpyAsync.  Default: the upload is one engine copy and the kernel, launched
+// at once, writes the pinned output as the input lands (both link directions busy; the call returns when both are
+// through).  --datacopyMode sequential: H2D, kernel and D2H queued back to back on one stream, as the reference
+// (cuda/bench_datatransfer.cu:62-75); the host blocks once, at the end.  Same bits either way.
 void DataTransferBenchmark::performBenchmarkIteration() {
+    if (link_plan_) {
+        checkGab(gab_datatransfer_round_trip(link_plan_, h_input_var, h_output_var, input_size, output_size, stream_),
+                 "gab_datatransfer_round_trip");
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(d_input_var, h_input_var, input_size_bytes, hipMemcpyHostToDevice, stream_));
     checkGab(gab_datatransfer(d_input_var, d_output_var, input_size, output_size, stream_), "gab_datatransfer");
     HIP_CHECK(hipMemcpyAsync(h_output_var, d_output_var, output_size_bytes, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+std::vector<GPUABenchmark::ResultArray> DataTransferBenchmark::resultArrays() const {
+    return {{"output", h_output_var, (size_t)output_size, 0, (size_t)output_size}};
 }
 
 void DataTransferBenchmark::validate(ValidationData& v) {

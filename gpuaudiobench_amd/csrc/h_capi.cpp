@@ -115,6 +115,7 @@ void gab_bench_default_config(gab_bench_config* c) {
     c->modal_mode = 0;
     c->conv_batch = 0;
     c->fdtd_form = 0;
+    c->datacopy_mode = 0;
 }
 
 int gab_bench_count(void) { return static_cast<int>(gab::benchmarkNames().size()); }
@@ -140,6 +141,7 @@ int gab_bench_create(gab_bench** out, const char* name, const gab_bench_config* 
         MODAL_REAL = c.modal_mode != 0;
         CONV_BATCH = c.conv_batch;
         FDTD_FORM = c.fdtd_form == 1 ? 1 : 0;
+        DATACOPY_SEQUENTIAL = c.datacopy_mode == 1 ? 1 : 0;
         auto impl = gab::createBenchmark(name);
         if (!impl) return gab::bad_arg("gab_bench_create: unknown benchmark name");
         auto* b = new gab_bench;

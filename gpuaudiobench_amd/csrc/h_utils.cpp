@@ -31,6 +31,7 @@ int MODAL_REAL = 0;
 int CONV_BATCH = 0;
 int FDTD_STEPS = 0;
 int FDTD_FORM = 0;
+int DATACOPY_SEQUENTIAL = 0;
 int CPU_THREADS = 0;
 bool GAB_QUIET = false;
 

@@ -4,7 +4,11 @@
 // every kernel is element- or wave-parallel with 16-byte coalesced accesses.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
+#include <memory>
 
 #include "gab_common.hpp"
 
@@ -139,6 +143,108 @@ __global__ __launch_bounds__(kBlock) void datatransfer_kernel(const float* __res
         out[i] = (i < in_size) ? in[i] : 0.5f + 0.5f * sinf((float)i * 0.001f);
 }
 
+// ---- datatransfer, both link directions at once ------------------------------------
+// gab_datatransfer_round_trip.  The reference moves the input up, runs its kernel and moves the output
+// down, one after the other (cuda/bench_datatransfer.cu:62-75).  Here (same findings as the convolver's
+// round trip, tools/ubench/link_modes): ONE engine copy of the input into `stage` (fine-grained device
+// memory: a running kernel sees it land) on the plan's own stream, and a kernel launched at once that
+// writes the pinned output itself — an engine upload beside shader writes to host memory runs both
+// directions at full rate.  The output is cut into 4 KiB chunks: the ones that need no input (the sine
+// tail) go first, the dependent ones follow in ascending order, dealt round-robin to the workgroups so
+// that they leave in the order the copy lands them.  A consumed input word is overwritten with a sentinel
+// (a NaN the benchmark's [0,1] input never holds); "my words are no longer the sentinel" means they have
+// landed, and an input that really holds it is released by the `landed` word the host sets once the copy's
+// event has completed.  Same expression per word as datatransfer_kernel: bit-identical output.
+constexpr unsigned kLinkSentinel = 0xffa5c3e1u;
+constexpr int kLinkPollLimit = 1 << 21;            // x ~0.5 us of s_sleep: about a second, then the launch gives up
+constexpr int kLinkChunk = 4 * kBlock;             // words per chunk: one float4 per thread
+struct LinkRoundTrip {
+    unsigned* stage;              // [>= in_size] fine-grained device memory, all sentinel between calls
+    float* h_out;                 // [out_size] pinned host memory
+    unsigned* counter;            // device: workgroups finished, runs on from call to call
+    unsigned* done;               // pinned host: the epoch, once h_out is complete
+    const unsigned* landed;       // pinned host: the epoch, once the host has seen the upload complete
+    unsigned* error;              // pinned host: nonzero if a wait ran out
+    unsigned epoch;
+    int in_size, out_size;
+};
+
+__device__ __forceinline__ unsigned link_peek(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRoundTrip rt) {
+    __shared__ int s_word;
+    const int tid = threadIdx.x;
+    const int dep = min(rt.in_size, rt.out_size);                    // outputs [0, dep) are input words
+    const int chunks = (rt.out_size + kLinkChunk - 1) / kLinkChunk;
+    const int dep_chunks = (dep + kLinkChunk - 1) / kLinkChunk;      // chunks that hold at least one input word
+    const int free_chunks = chunks - dep_chunks;
+    bool gave_up = false;
+    for (int pos = blockIdx.x; pos < chunks; pos += gridDim.x) {
+        const int chunk = pos < free_chunks ? dep_chunks + pos : pos - free_chunks;
+        const int w0 = chunk * kLinkChunk + 4 * tid;                  // this thread's four words
+        const int n_in = max(0, min(4, dep - w0));                    // how many of them are input words
+        unsigned w[4] = {0, 0, 0, 0};
+        if (chunk < dep_chunks) {
+            // one lane watches the chunk's last input word; then every lane checks its own (the copy need not
+            // land in ascending order)
+            if (tid == 0) {
+                const unsigned* const last = rt.stage + min(chunk * kLinkChunk + kLinkChunk, dep) - 1;
+                int tries = 0, bad = gave_up ? 1 : 0;
+                while (!bad && link_peek(last) == kLinkSentinel) {
+                    if ((++tries & 63) == 0 && link_peek(rt.landed) == rt.epoch) break;     // the upload is in: it IS the sentinel
+                    if (tries > kLinkPollLimit) { bad = 1; break; }
+                    __builtin_amdgcn_s_sleep(20);
+                }
+                s_word = bad;
+            }
+            __syncthreads();
+            if (s_word) gave_up = true;
+            __syncthreads();                                          // s_word is free for the next chunk
+            int tries = 0;
+            for (;;) {
+                bool all = true;
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_in) { w[k] = link_peek(rt.stage + w0 + k); all = all && w[k] != kLinkSentinel; }
+                if (all || gave_up) break;
+                if ((++tries & 15) == 0 && link_peek(rt.landed) == rt.epoch) {              // landed for good: one more look
+                    for (int k = 0; k < 4; ++k)
+                        if (k < n_in) w[k] = link_peek(rt.stage + w0 + k);
+                    break;
+                }
+                if (tries > kLinkPollLimit) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(10);
+            }
+            for (int k = 0; k < 4; ++k)                               // taken: the sentinel goes back for the next call
+                if (k < n_in) __hip_atomic_store(rt.stage + w0 + k, kLinkSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v val;
+        for (int k = 0; k < 4; ++k) {
+            const int i = w0 + k;
+            val[k] = (k < n_in) ? __uint_as_float(w[k]) : 0.5f + 0.5f * sinf((float)i * 0.001f);
+        }
+        float* const dst = rt.h_out + w0;
+        if (w0 + 4 <= rt.out_size) {
+            // system-scope write-through: nothing of it stays behind in a cache
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (w0 + k < rt.out_size) __hip_atomic_store(dst + k, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // every wave waits until the link's ordered queue has accepted its rows, THEN the workgroup counts as finished:
+    // the workgroup whose count completes the launch issues the completion word behind every row
+    if (gave_up) __hip_atomic_store(rt.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(rt.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == rt.epoch * gridDim.x) __hip_atomic_store(rt.done, rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- modal (placeholder semantics) ---------------------------------------------
 // One workgroup per output row; only params[8*i] of the first out_tracks modes
 // can reach the output in the reference kernel.
@@ -250,6 +356,142 @@ int gab_datatransfer(const float* d_in, float* d_out, int in_size, int out_size,
         gab::datatransfer_kernel<<<gab::grid_for((size_t)out_size), gab::kBlock, 0, gab::as_stream(stream)>>>(
             d_in, d_out, in_size, out_size);
         return gab::launch_status("datatransfer_kernel");
+    });
+}
+
+struct gab_link_plan {
+    int max_in = 0;
+    int workgroups = 256;
+    unsigned* stage = nullptr;        // fine-grained device memory, max_in words
+    unsigned* counter = nullptr;      // device
+    unsigned* words = nullptr;        // pinned: [0] done, [16] landed, [32] error
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev = nullptr;
+    unsigned epoch = 0;
+    const void* checked_out = nullptr;
+    // input words an earlier call uploaded but did not consume (its input was longer than its output): they hold
+    // data, not the sentinel, and a later call that reads them must find the sentinel first
+    int stale_lo = 0, stale_hi = 0;
+    ~gab_link_plan() {
+        if (stage) (void)hipFree(stage);
+        if (counter) (void)hipFree(counter);
+        if (words) (void)hipHostFree(words);
+        if (copy_ev) (void)hipEventDestroy(copy_ev);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};
+
+int gab_link_plan_create(int max_in_size, gab_link_plan** out) {
+    return gab::guarded([&]() -> int {
+        if (!out) return gab::bad_arg("gab_link_plan_create: null argument");
+        *out = nullptr;
+        if (max_in_size < 0) return gab::bad_arg("gab_link_plan_create: negative size");
+        std::unique_ptr<gab_link_plan> p(new gab_link_plan);
+        p->max_in = max_in_size;
+        const size_t n = (size_t)std::max(max_in_size, 4);
+        GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->stage), n * 4, hipDeviceMallocFinegrained));
+        GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, n));
+        GAB_HIP_CHECK(hipMalloc(&p->counter, 128));
+        GAB_HIP_CHECK(hipMemset(p->counter, 0, 128));
+        GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->words), 64 * sizeof(unsigned), hipHostMallocDefault));
+        for (int i = 0; i < 64; ++i) p->words[i] = 0;
+        GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        GAB_HIP_CHECK(hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming));
+#ifdef GAB_ABLATE
+        if (getenv("GAB_LINK_WGS")) p->workgroups = std::max(1, atoi(getenv("GAB_LINK_WGS")));
+#endif
+        GAB_HIP_CHECK(hipDeviceSynchronize());
+        *out = p.release();
+        return GAB_OK;
+    });
+}
+
+void gab_link_plan_destroy(gab_link_plan* p) {
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    delete p;
+}
+
+int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_out, int in_size, int out_size,
+                                gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!p) return gab::bad_arg("gab_datatransfer_round_trip: null plan");
+        if (in_size < 0 || out_size < 0) return gab::bad_arg("gab_datatransfer_round_trip: negative size");
+        if (in_size > p->max_in) return gab::bad_arg("gab_datatransfer_round_trip: in_size exceeds the plan's max_in_size");
+        if ((!h_in && in_size) || (!h_out && out_size)) return gab::bad_arg("gab_datatransfer_round_trip: null pointer");
+        hipStream_t s = gab::as_stream(stream);
+        if (out_size && p->checked_out != h_out) {     // the kernel writes h_out itself: it must be mapped into the device
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, h_out) != hipSuccess || at.devicePointer == nullptr) {
+                (void)hipGetLastError();
+                return gab::bad_arg("gab_datatransfer_round_trip: h_out must be pinned host memory (hipHostMalloc) or device memory");
+            }
+            p->checked_out = h_out;
+        }
+        const int dep = std::min(in_size, out_size);
+        if (p->stale_hi > p->stale_lo && dep > p->stale_lo) {
+            // this call reads words an earlier one left unconsumed: the sentinel goes back, ahead of the upload on its
+            // stream, and the kernel's stream waits for it (steady repeats of one shape never come here)
+            GAB_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->stage + p->stale_lo), (int)gab::kLinkSentinel,
+                                            (size_t)(p->stale_hi - p->stale_lo), p->copy_stream));
+            GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
+            GAB_HIP_CHECK(hipStreamWaitEvent(s, p->copy_ev, 0));
+            p->stale_lo = p->stale_hi = 0;
+        }
+        if (in_size)
+            GAB_HIP_CHECK(hipMemcpyAsync(p->stage, h_in, sizeof(float) * (size_t)in_size, hipMemcpyHostToDevice, p->copy_stream));
+        if (in_size > out_size) {
+            p->stale_lo = p->stale_hi > p->stale_lo ? std::min(p->stale_lo, out_size) : out_size;
+            p->stale_hi = std::max(p->stale_hi, in_size);
+        }
+        if (out_size == 0) {                            // nothing comes back: the call is the upload
+            GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
+            return GAB_OK;
+        }
+        const unsigned epoch = ++p->epoch;
+        volatile unsigned* const done = p->words;
+        volatile unsigned* const landed = p->words + 16;
+        volatile unsigned* const error = p->words + 32;
+        gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, epoch, in_size, out_size};
+        gab::datatransfer_round_trip_kernel<<<dim3(p->workgroups), dim3(gab::kBlock), 0, s>>>(rt);
+        int rc = gab::launch_status("datatransfer_round_trip_kernel");
+        if (in_size) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
+        if (rc) {
+            (void)hipStreamSynchronize(p->copy_stream);
+            return rc;
+        }
+        // the pinned word says the output is complete; the upload's event releases workgroups whose words really hold
+        // the sentinel.  The call returns when BOTH directions are through (an input longer than the output is still
+        // landing when the last output has left).
+        bool told = in_size == 0;
+        if (told) *landed = epoch;
+        // after a wait that ran out, words may have landed behind their sentinel: the launch bounds its own waits, so let
+        // it end (also before the caller may free the buffers), then start the next call from an all-sentinel stage
+        auto repoison = [&]() {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(p->copy_stream);
+            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, (size_t)std::max(p->max_in, 4));
+            (void)hipDeviceSynchronize();
+            p->stale_lo = p->stale_hi = 0;
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*done != epoch || !told) {
+            if (!told && hipEventQuery(p->copy_ev) == hipSuccess) { *landed = epoch; told = true; }
+            if ((++spins & 1023u) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+                repoison();
+                gab::set_last_error("gab_datatransfer_round_trip: the launch did not report completion within 4 s; the output of this call is invalid");
+                return GAB_ERR_RUNTIME;
+            }
+        }
+        if (*error != 0) {
+            *error = 0;
+            repoison();
+            gab::set_last_error("gab_datatransfer_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
+            return GAB_ERR_RUNTIME;
+        }
+        return GAB_OK;
     });
 }
 

@@ -80,6 +80,39 @@ def datatransfer(x, out_size):
     return out
 
 
+class LinkPlan:
+    """gab_link_plan: the staging buffer, words and upload stream of datatransfer with both link directions
+    busy at once (gab_datatransfer_round_trip)."""
+
+    def __init__(self, max_in_size):
+        h = C.c_void_p()
+        check(lib.gab_link_plan_create(int(max_in_size), C.byref(h)))
+        self._h, self.max_in_size = h, int(max_in_size)
+
+    def round_trip(self, h_in, h_out, stream=None):
+        """Pinned host tensor in -> pinned host tensor out; returns when h_out is complete and h_in uploaded."""
+        if h_in.is_cuda or h_out.is_cuda or (h_out.numel() and not h_out.is_pinned()):
+            raise TypeError("round_trip takes host tensors; the output must be pinned")
+        if h_in.dtype != torch.float32 or h_out.dtype != torch.float32 or not h_in.is_contiguous() or not h_out.is_contiguous():
+            raise TypeError("round_trip takes contiguous float32 tensors")
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        check(lib.gab_datatransfer_round_trip(self._h, C.c_void_p(h_in.data_ptr()) if h_in.numel() else None,
+                                              C.c_void_p(h_out.data_ptr()) if h_out.numel() else None,
+                                              h_in.numel(), h_out.numel(), st))
+        return h_out
+
+    def close(self):
+        if self._h:
+            lib.gab_link_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def iir(x, coeffs, state, tracks, bufsize, sequential=False):
     """state (tracks*2, device) is updated in place.  sequential=True forces the
     lane-per-track kernel that is bit-identical to the golden."""

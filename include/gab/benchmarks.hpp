@@ -112,6 +112,7 @@ public:
     size_t algorithmicBytes() const override;
     int inputSize() const { return input_size; }
     int outputSize() const { return output_size; }
+    std::vector<ResultArray> resultArrays() const override;
 
 private:
     Config config_;
@@ -120,6 +121,7 @@ private:
     float* d_input_var = nullptr;
     float* d_output_var = nullptr;
     float* cpu_reference = nullptr;
+    struct gab_link_plan* link_plan_ = nullptr;   // DATACOPY_SEQUENTIAL == 0: gab_datatransfer_round_trip
     int input_size;
     int output_size;
     size_t input_size_bytes;

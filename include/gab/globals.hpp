@@ -43,5 +43,7 @@ std::string generateJSONResultsWith(const std::vector<float>& vec, const std::st
 extern int CONV_BATCH;           // --convBatch    (<=1: one buffer per iteration with its H2D / D2H copies, as the reference;
                                  //                 n: n HBM-resident buffers per iteration in ONE gab_conv_process_batch launch)
 extern int FDTD_FORM;            // --fdtdForm     (0 auto: LDS-resident where the room fits, 1 step: one launch per step)
+extern int DATACOPY_SEQUENTIAL;  // --datacopyMode (0 overlap: upload and download at once, gab_datatransfer_round_trip;
+                                 //                 1 sequential: H2D -> kernel -> D2H on one stream, as the reference)
 extern int FDTD_STEPS;           // --fdtdSteps    (<=0: bufferSize samples x 3 steps, as the reference)
 extern int CPU_THREADS;          // --cpu-threads  (<=0: every hardware thread) for the timed CPU golden

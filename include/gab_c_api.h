@@ -65,6 +65,20 @@ int gab_gainstats(const float* d_in, float* d_out, float* d_stats, int tracks,
 int gab_datatransfer(const float* d_in, float* d_out, int in_size, int out_size,
                      gab_stream_t stream);
 
+/* The same operation with both link directions busy at once (replaces the reference's H2D -> kernel -> D2H
+ * sequence around DataTransferKernel, cuda/bench_datatransfer.cu:62-75, in one call).  h_in [in_size] is any
+ * host memory hipMemcpyAsync accepts (pinned for full rate); h_out [out_size] MUST be pinned (hipHostMalloc) or
+ * device memory: the kernel writes it itself while ONE engine copy of h_in lands in the plan's staging buffer.
+ * Returns when h_out is complete AND the whole input has been uploaded; bit-identical to gab_datatransfer on the
+ * uploaded input.  in_size <= the plan's max_in_size.  The call blocks (it is the benchmark's timed unit); `stream`
+ * carries the kernel.  One call at a time per plan.  GAB_ERR_RUNTIME: a wait inside the launch ran out (about a
+ * second) — h_out is then invalid and the plan has been re-armed for the next call.                              */
+typedef struct gab_link_plan gab_link_plan;
+int gab_link_plan_create(int max_in_size, gab_link_plan** out);
+void gab_link_plan_destroy(gab_link_plan* plan);
+int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h_out, int in_size, int out_size,
+                                gab_stream_t stream);
+
 /* IIRFilterKernel (cuda/bench_iir.cu:10-44): DF-II biquad per track,
  * coeffs = {b0,b1,b2,a1,a2} (HOST pointer, 5 floats), d_state = T x {z1,z2}
  * read and written back.
@@ -384,6 +398,8 @@ typedef struct {
                                reference); n: n HBM-resident buffers per iteration in ONE
                                gab_conv_process_batch launch (throughput mode)           */
     int    fdtd_form;       /* FDTD3D: GAB_FDTD_FORM_AUTO (0) | GAB_FDTD_FORM_STEP (1)              */
+    int    datacopy_mode;   /* datacopy*: 0 upload and download at once (gab_datatransfer_round_trip)
+                               | 1 H2D -> kernel -> D2H one after the other (the reference's schedule) */
 } gab_bench_config;
 
 typedef struct {

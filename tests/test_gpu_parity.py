@@ -97,6 +97,54 @@ def test_datatransfer(gab, orc, rin, rout):
     assert peak_err(y, ref) <= TOL
 
 
+@pytest.mark.parametrize("n_in,n_out", [(26214, 2595225), (524288, 2097152), (1310720, 1310720), (2097152, 524288),
+                                        (2595225, 26214), (1, 1), (3, 7), (7, 3), (1025, 1023), (0, 5000), (4097, 0),
+                                        (1024, 1024), (5000, 4096)])
+def test_datatransfer_round_trip_is_the_device_kernel_bit_for_bit(gab, orc, n_in, n_out):
+    """Upload and download at once (gab_datatransfer_round_trip) against the device-buffer kernel on the same input:
+    identical bits, ragged sizes included; the copied part equals the input exactly.  The plan is reused."""
+    import torch
+    plan = gab.LinkPlan(max(n_in, 1))
+    for rep in range(3):
+        x = orc.Rand(1 + rep).unit(n_in)
+        h_in = torch.from_numpy(x).pin_memory()
+        h_out = torch.full((n_out,), -7.0).pin_memory()
+        plan.round_trip(h_in, h_out)
+        ref = host(gab.datatransfer(dev(x), n_out)) if n_out else np.zeros(0, np.float32)
+        assert np.array_equal(bits(h_out.numpy()), bits(ref)), "call %d" % rep
+        m = min(n_in, n_out)
+        assert np.array_equal(bits(h_out.numpy()[:m]), bits(x[:m]))
+        assert peak_err(h_out.numpy(), orc.datatransfer(x, n_out)) <= TOL if n_out else True
+    plan.close()
+
+
+def test_datatransfer_round_trip_input_that_holds_the_sentinel_and_smaller_calls(gab, orc):
+    """Input words that really are the staging sentinel are released by the upload's event (slower, never wrong);
+    a later, shorter call on the same plan does not see what an earlier, longer one left behind."""
+    import torch
+    n = 300000
+    plan = gab.LinkPlan(n)
+    x = orc.Rand(5).unit(n)
+    xb = x.view(np.uint32).copy()
+    xb[::7] = 0xffa5c3e1
+    xb[-1] = 0xffa5c3e1
+    h_in = torch.from_numpy(xb.view(np.float32).copy()).pin_memory()
+    h_out = torch.zeros(n + 1000).pin_memory()
+    for _ in range(2):
+        plan.round_trip(h_in, h_out)
+        assert np.array_equal(bits(h_out.numpy()[:n]), xb)
+    for m_in, m_out in ((1000, 200000), (123457, 123457), (n, 10), (n, n), (n - 5, 77), (n, n + 9), (50, 0), (n, 3000)):
+        y = orc.Rand(m_in).unit(m_in)
+        h_o = torch.zeros(m_out).pin_memory()
+        plan.round_trip(torch.from_numpy(y).pin_memory(), h_o)
+        assert np.array_equal(bits(h_o.numpy()), bits(host(gab.datatransfer(dev(y), m_out))))
+    with pytest.raises(gab.GabError):
+        plan.round_trip(torch.zeros(n + 1).pin_memory(), h_out)          # longer than the plan
+    with pytest.raises(TypeError):
+        plan.round_trip(h_in, torch.zeros(16))                           # pageable output
+    plan.close()
+
+
 @pytest.mark.parametrize("T,B", [(128, 512), (5, 100), (200, 513)])
 def test_iir_sequential_bit_exact_with_carried_state(gab, orc, T, B):
     c = orc.iir_coeffs(0.25)
