@@ -43,6 +43,9 @@ CASES = {
     "datacopy0199": ("datacopy0199", dict(), 200), "datacopy2080": ("datacopy2080", dict(), 200),
     "datacopy5050": ("datacopy5050", dict(), 200), "datacopy8020": ("datacopy8020", dict(), 200),
     "datacopy9901": ("datacopy9901", dict(), 200),
+    "datacopy0199_seq": ("datacopy0199", dict(datacopy_mode=1), 200), "datacopy2080_seq": ("datacopy2080", dict(datacopy_mode=1), 200),
+    "datacopy5050_seq": ("datacopy5050", dict(datacopy_mode=1), 200), "datacopy8020_seq": ("datacopy8020", dict(datacopy_mode=1), 200),
+    "datacopy9901_seq": ("datacopy9901", dict(datacopy_mode=1), 200),
     "fdtd_52": ("FDTD3D", dict(n_tracks=128, buffer_size=128), 20),
     "fdtd_128": ("FDTD3D", dict(n_tracks=128, buffer_size=128, fdtd_grid=128), 10),
     "noop_128": ("NoOp", dict(n_tracks=128), 300),
@@ -71,10 +74,17 @@ def run(case, iters=None):
     row = dict(case=case, benchmark=name, config=cfg, iterations=n, wall_median_ms=r.median_ms, wall_p95_ms=r.p95_ms,
                device_median_ms=r.gpu_median_ms, algorithmic_bytes=alg, valid=(v.status == 0), max_error=v.max_error)
     if name.startswith("datacopy"):
-        # in + out bytes over the link; device_median = H2D + kernel + D2H on one stream (events around all three)
+        # in + out bytes over the link.  Sequential (datacopy_mode 1): the directions take turns, the bound is the sum
+        # of both at the link's one-way rate.  Overlap (default): both at once, the bound is the LARGER direction alone.
+        import numpy as np
+        base = 10 * 1024 * 1024 // 4
+        n_in, n_out = int(base * np.float32(int(name[8:10]) / 100.0)), int(base * np.float32(int(name[10:12]) / 100.0))
+        assert 4 * (n_in + n_out) == alg, (n_in, n_out, alg)
         row["link_GBps_device"] = alg / (r.gpu_median_ms * 1e-3) / 1e9 if r.gpu_median_ms > 0 else None
         row["link_GBps_wall"] = alg / (r.median_ms * 1e-3) / 1e9
-        row["frac_of_pcie_gen5_x16"] = row["link_GBps_wall"] / PCIE_GEN5_X16_GBS
+        bound_bytes = alg if cfg.get("datacopy_mode") == 1 else 4 * max(n_in, n_out)
+        row["link_bound"] = "both directions in turn" if cfg.get("datacopy_mode") == 1 else "the larger direction"
+        row["frac_of_pcie_gen5_x16"] = bound_bytes / (r.median_ms * 1e-3) / 1e9 / PCIE_GEN5_X16_GBS
     print(json.dumps(row), flush=True)
     b.close()
 
@@ -102,6 +112,7 @@ def collect(d, out_csv, out_md):
         bf = os.path.join(ROOT, "profiles", "r04_fdtd_bound.json")
         if case in FDTD_RESIDENT_FLOOR_US_PER_STEP and os.path.exists(bf):
             floor = json.load(open(bf)).get(case, {}).get("floor_us_per_step")
+        link = case.startswith("datacopy")        # the iteration is bound by the link, whatever kernel runs beside the copies
         for r in ks:
             calls = int(r["Calls"])
             rows.append(dict(case=case, benchmark=meta["benchmark"], kernel=short(r["Name"]), calls=calls,
@@ -110,9 +121,10 @@ def collect(d, out_csv, out_md):
                              algorithmic_bytes=kbytes,
                              alg_GBps=kbytes / per_iter_ns if per_iter_ns > 0 else 0.0,
                              # rooms resident in LDS: not an HBM figure at all — the fraction is of the kernel's own floor
-                             frac_of_8TBps=(kbytes / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0) if floor is None else None,
-                             bound=("hbm" if floor is None else "issue + neighbour hand-off, %.2f us per step" % floor),
-                             frac_of_bound=(None if floor is None else
+                             frac_of_8TBps=(kbytes / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0) if floor is None and not link else None,
+                             bound=("PCIe Gen5 x16, 63 GB/s one way, %s" % meta.get("link_bound", "") if link else
+                                    "hbm" if floor is None else "issue + neighbour hand-off, %.2f us per step" % floor),
+                             frac_of_bound=(meta.get("frac_of_pcie_gen5_x16") if link else None if floor is None else
                                             floor * meta["config"].get("buffer_size", 512) * 3 / (per_iter_ns / 1e3)),
                              harness_device_median_us=meta["device_median_ms"] * 1e3, wall_median_us=meta["wall_median_ms"] * 1e3,
                              valid=meta["valid"], link_GBps_wall=meta.get("link_GBps_wall"),
@@ -124,8 +136,10 @@ def collect(d, out_csv, out_md):
         w.writerows(rows)
     with open(out_md, "w") as f:
         f.write("Per-kernel, per-size device times (rocprofv3 --kernel-trace --stats, ONE pass per case; `kernels us/iter` = all\n"
-                "gab kernels of one harness iteration; frac = algorithmic bytes / that time / 8 TB/s; datacopy rows: link GB/s\n"
-                "= (in + out bytes) / wall median of H2D + kernel + D2H, against PCIe Gen5 x16 = 63 GB/s per direction).\n\n")
+                "gab kernels of one harness iteration; frac = algorithmic bytes / that time / 8 TB/s.  datacopy rows: link GB/s\n"
+                "= (in + out bytes) / wall median of the iteration; their fraction is of PCIe Gen5 x16's 63 GB/s one way — of the\n"
+                "LARGER direction's bytes / wall for the default overlapped schedule (both directions at once: the kernel in the row\n"
+                "runs for the whole transfer), of in + out bytes / wall for `_seq` (H2D, kernel, D2H in turn, the reference's).\n\n")
         f.write("Rooms the FDTD3D kernel keeps resident in LDS cross no HBM roofline: their fraction is of the kernel's own per-step floor\n"
                 "(profiles/r04_fdtd_bound.md).  The modal placeholder's kernel is priced against the 66 560 B it reads and writes (its\n"
                 "iteration is the 32 MiB upload).\n\n")
