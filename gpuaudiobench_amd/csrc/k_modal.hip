@@ -53,7 +53,10 @@ __device__ __forceinline__ cf mul_by_hi(cf st, cf cs) {
 // loop over it unrolls and the wave fold is one cross-half add); TRACKS == 0 takes it at run time.
 // (Measured and not kept: two modes per packed register (RE, IM, C, S, AMP pairs), 4.5 instead
 // of 5 instructions per mode-sample but half as many lanes busy: 144 vs 125 us at 2^20 modes —
-// with two or more waves per SIMD unpacked fp32 already issues at the packed rate.)
+// with two or more waves per SIMD unpacked fp32 already issues at the packed rate.  Round 4: sample-outer / mode-inner
+// order, so that no instruction waits for the one before it: 112 against 113 us, the same.  What the 5-instruction
+// floor (68 us at 2.4 GHz) does not hold: the double-precision sincos per mode (~12 %), the folds (~20 %), the clock
+// under packed-fp32 load (~2.2 GHz).)
 template <int J, int TRACKS>
 __global__ __launch_bounds__(kMbThreads, 4) void modal_bank_kernel(const float* __restrict__ params,
                                                                float* __restrict__ partial,
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(kMbThreads, 4) void modal_bank_kernel(const float* 
     __shared__ float fold[2][kMbWaves][65 * kMbChunk];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int waves = blockDim.x >> 6;
+    constexpr int waves = kMbWaves;                  // every launch is kMbThreads wide (modal_launch)
     const int slots = 64 / tracks;
     const int track = lane % tracks, slot = lane / tracks;
     const bool serving = slot < slots;
@@ -139,11 +142,15 @@ __global__ __launch_bounds__(kMbThreads, 4) void modal_bank_kernel(const float* 
         // One barrier per chunk (the next chunk writes the other parity).  LDS-only: a full
         // __syncthreads() also waits for the previous chunk's global stores (vmcnt).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int e = tid; e < tracks * kMbChunk; e += (int)blockDim.x) {
+        for (int e = tid; e < tracks * kMbChunk; e += kMbThreads) {
             const int t = e / kMbChunk, ii = e % kMbChunk;
             const int at = ii * (tracks + 1) + t;
-            float sum = fold[c & 1][0][at];
-            for (int ww = 1; ww < waves; ++ww) sum = __fadd_rn(sum, fold[c & 1][ww][at]);
+            float part[kMbWaves];
+#pragma unroll
+            for (int ww = 0; ww < kMbWaves; ++ww) part[ww] = fold[c & 1][ww][at];      // all in flight, then wave order
+            float sum = part[0];
+#pragma unroll
+            for (int ww = 1; ww < kMbWaves; ++ww) sum = __fadd_rn(sum, part[ww]);
             const int i = c * kMbChunk + ii;
             if (i < B) mine[(size_t)t * B + i] = sum;
         }

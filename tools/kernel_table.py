@@ -59,6 +59,13 @@ KERNEL_BYTES = {"modal_placeholder": 32 * 8 * 4 + 32 * 512 * 4}
 # The LDS-resident FDTD kernel moves no field through HBM: its per-step floor is the longer of (a) VALU issue — the
 # counted instructions per SIMD and step x 4 cycles per wave64 instruction at the part's clock — and (b) the neighbour
 # hand-off's request-to-data round trip with every workgroup asking at once; profiles/r04_fdtd_bound.md holds both.
+# The modal bank is VALU-bound: the golden's own phasor recurrence (unfused, so that every mode's sequence is the
+# oracle's bit for bit) is 3 packed + 2 plain fp32 instructions per mode and sample; a SIMD issues one wave64
+# instruction per 4 clocks.  Floor = modes x samples x 5 / 64 lanes / 1024 SIMDs x 4 clk / 2.4 GHz.
+def modal_bank_floor_us(n_modes, bufsize):
+    return n_modes * bufsize * 5.0 / 64 / 1024 * 4 / 2.4e3
+
+
 FDTD_RESIDENT_FLOOR_US_PER_STEP = {"fdtd_128": None, "fdtd_52": None}     # filled from profiles/r04_fdtd_bound.json when present
 
 
@@ -113,6 +120,10 @@ def collect(d, out_csv, out_md):
         if case in FDTD_RESIDENT_FLOOR_US_PER_STEP and os.path.exists(bf):
             floor = json.load(open(bf)).get(case, {}).get("floor_us_per_step")
         link = case.startswith("datacopy")        # the iteration is bound by the link, whatever kernel runs beside the copies
+        valu_floor = None
+        if case.startswith("modal_bank"):
+            nt = meta["config"].get("n_tracks", 128)
+            valu_floor = modal_bank_floor_us(min(1024 * nt, 1024 * 1024), meta["config"].get("buffer_size", 512))
         for r in ks:
             calls = int(r["Calls"])
             rows.append(dict(case=case, benchmark=meta["benchmark"], kernel=short(r["Name"]), calls=calls,
@@ -121,10 +132,12 @@ def collect(d, out_csv, out_md):
                              algorithmic_bytes=kbytes,
                              alg_GBps=kbytes / per_iter_ns if per_iter_ns > 0 else 0.0,
                              # rooms resident in LDS: not an HBM figure at all — the fraction is of the kernel's own floor
-                             frac_of_8TBps=(kbytes / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0) if floor is None and not link else None,
+                             frac_of_8TBps=(kbytes / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0) if floor is None and not link and valu_floor is None else None,
                              bound=("PCIe Gen5 x16, 63 GB/s one way, %s" % meta.get("link_bound", "") if link else
+                                    "VALU issue, 5 instr per mode-sample: %.1f us" % valu_floor if valu_floor is not None else
                                     "hbm" if floor is None else "issue + neighbour hand-off, %.2f us per step" % floor),
-                             frac_of_bound=(meta.get("frac_of_pcie_gen5_x16") if link else None if floor is None else
+                             frac_of_bound=(meta.get("frac_of_pcie_gen5_x16") if link else
+                                            valu_floor / (per_iter_ns / 1e3) if valu_floor is not None else None if floor is None else
                                             floor * meta["config"].get("buffer_size", 512) * 3 / (per_iter_ns / 1e3)),
                              harness_device_median_us=meta["device_median_ms"] * 1e3, wall_median_us=meta["wall_median_ms"] * 1e3,
                              valid=meta["valid"], link_GBps_wall=meta.get("link_GBps_wall"),
