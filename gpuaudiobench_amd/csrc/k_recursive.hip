@@ -251,67 +251,176 @@ inline IirScanConsts make_scan_consts(const BiquadCoeffs& c, int M) {
 // ---------------------------------------------------------------------------
 // conv1d: y[t*B+i] = sum_j h[t*L+j] * xflat[t*B+i-j], j ascending, with the
 // golden's range test on the FLAT index (cuda/bench_conv1d.cu:188-208).  One
-// workgroup = 256 consecutive outputs of one track; taps and the input window
-// are staged in LDS in chunks of kTapChunk taps.
+// workgroup = 256 consecutive outputs of one track; the input window is staged
+// in LDS in chunks of kTapChunk taps.
 //
 // The sum is a strictly ordered chain of roundings (that is what makes it
-// bit-identical to the golden), so the only freedom is to keep everything else
-// off that chain: the products, and the LDS reads, which run one group of 16
-// taps ahead of the adds that use them (two register sets; taps are read as
-// broadcasts from LDS rather than through the scalar cache, because LDS returns
-// in order and can be waited for by count).  A kernel lasts as long as its
-// longest chain, so the tiles at the very start of the stream — where the
-// golden SKIPS the taps that reach before sample 0 — run the same pipeline with
-// a select on the chain instead of a branch (START).
+// bit-identical to the golden): an output is ONE chain, a wave has 64 of them
+// and nothing more, so a tile lasts (taps) x (what one chain step costs the
+// wave).  One wave issues a dependent add every 5.25 clocks and any other fp32
+// instruction in ~4 (tools/ubench/dep_chain), so add + product is ~9 clocks per
+// tap; the rest is kept off the wave's instruction stream or out of its waits:
+// the taps are wave-uniform scalar loads (no LDS cycles: at C2, 8 waves per CU,
+// the window reads alone are 16 of the LDS's clocks per tap); requests run one
+// group of 32 taps ahead in a hand-fixed order (tap_group_*); the tiles at the
+// very start of the stream — where the golden SKIPS the taps that reach before
+// sample 0 — need no select with finite taps (see the kernel).
+// Measured (tools/stamp_conv1d.py): 29 -> 13 clocks per tap at 1024 taps
+// (one wave per SIMD), 30 -> 18 at C2 (two per SIMD, LDS-bound).
 // ---------------------------------------------------------------------------
+#ifdef GAB_ABLATE
+// diagnostic builds: s_memtime of workgroup (1, 7), thread 0 — [0] tile entered, [1] window staged, [2] chain done, [3] back
+__device__ unsigned long long g_c1_stamps[4];
+#define GAB_C1_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 7) g_c1_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GAB_C1_STAMP(i) do {} while (0)
+#endif
 constexpr int kTapChunk = 1024;
 constexpr int kConvTile = 256;
 constexpr int kTapGroup = 16;
+constexpr int kWinPad = 32;            // >= the largest prefetch group
+
+// One group of 16 taps in flight: the lane's 16 window samples (x[k] = w[-at-k], as pairs) and the track's 16 taps
+// (wave-uniform, SGPRs).  Requested and waited for by hand: scalar loads return out of order, so the only wait that
+// covers them is lgkmcnt(0), which takes every LDS read in flight with it — the compiler, which places its waits at the
+// first use, therefore waits for the NEXT group's requests as well (29 clocks per tap measured, against ~9 for the
+// chain itself: tools/ubench/dep_chain).  Here the order is fixed: wait for the group about to be used, request the
+// next, then run the 16 steps, so that requests have a whole group's chain to come back in.
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int kTapSet = 32;            // taps per hand-ordered group: the lead a request has is one group's chain (~270 clocks)
+struct TapGroup {
+    f2v x[16];
+    f16v h0, h1;
+};
+// lds_lowest: LDS byte address of w[-at-31]; taps: &h[at] (wave-uniform).
+// (`acc` passes through both statements: the chain is the only thing the compiler could otherwise move across them)
+__device__ __forceinline__ void tap_group_request(TapGroup& g, unsigned lds_lowest, const float* taps, float& acc) {
+    asm volatile(
+        "ds_read2_b32 %0, %19 offset0:31 offset1:30\n\t"
+        "ds_read2_b32 %1, %19 offset0:29 offset1:28\n\t"
+        "ds_read2_b32 %2, %19 offset0:27 offset1:26\n\t"
+        "ds_read2_b32 %3, %19 offset0:25 offset1:24\n\t"
+        "ds_read2_b32 %4, %19 offset0:23 offset1:22\n\t"
+        "ds_read2_b32 %5, %19 offset0:21 offset1:20\n\t"
+        "ds_read2_b32 %6, %19 offset0:19 offset1:18\n\t"
+        "ds_read2_b32 %7, %19 offset0:17 offset1:16\n\t"
+        "ds_read2_b32 %8, %19 offset0:15 offset1:14\n\t"
+        "ds_read2_b32 %9, %19 offset0:13 offset1:12\n\t"
+        "ds_read2_b32 %10, %19 offset0:11 offset1:10\n\t"
+        "ds_read2_b32 %11, %19 offset0:9 offset1:8\n\t"
+        "ds_read2_b32 %12, %19 offset0:7 offset1:6\n\t"
+        "ds_read2_b32 %13, %19 offset0:5 offset1:4\n\t"
+        "ds_read2_b32 %14, %19 offset0:3 offset1:2\n\t"
+        "ds_read2_b32 %15, %19 offset0:1 offset1:0\n\t"
+        "s_load_dwordx16 %16, %20, 0x0\n\t"
+        "s_load_dwordx16 %17, %20, 0x40"
+        : "=&v"(g.x[0]), "=&v"(g.x[1]), "=&v"(g.x[2]), "=&v"(g.x[3]), "=&v"(g.x[4]), "=&v"(g.x[5]), "=&v"(g.x[6]), "=&v"(g.x[7]),
+          "=&v"(g.x[8]), "=&v"(g.x[9]), "=&v"(g.x[10]), "=&v"(g.x[11]), "=&v"(g.x[12]), "=&v"(g.x[13]), "=&v"(g.x[14]), "=&v"(g.x[15]),
+          "=&s"(g.h0), "=&s"(g.h1), "+v"(acc)
+        : "v"(lds_lowest), "s"(taps)
+        : "memory");
+}
+// Everything requested so far has arrived.  The group passes THROUGH the statement, so nothing reads it earlier.
+__device__ __forceinline__ void tap_group_arrive(TapGroup& g, float& acc) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(g.x[0]), "+v"(g.x[1]), "+v"(g.x[2]), "+v"(g.x[3]), "+v"(g.x[4]), "+v"(g.x[5]), "+v"(g.x[6]), "+v"(g.x[7]),
+                   "+v"(g.x[8]), "+v"(g.x[9]), "+v"(g.x[10]), "+v"(g.x[11]), "+v"(g.x[12]), "+v"(g.x[13]), "+v"(g.x[14]), "+v"(g.x[15]),
+                   "+s"(g.h0), "+s"(g.h1), "+v"(acc)
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ float tap_group_chain(const TapGroup& g, float acc) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        acc = __fadd_rn(acc, __fmul_rn(g.h0[2 * p], g.x[p].x));
+        acc = __fadd_rn(acc, __fmul_rn(g.h0[2 * p + 1], g.x[p].y));
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        acc = __fadd_rn(acc, __fmul_rn(g.h1[2 * p], g.x[8 + p].x));
+        acc = __fadd_rn(acc, __fmul_rn(g.h1[2 * p + 1], g.x[8 + p].y));
+    }
+    return acc;
+}
 
 template <bool START>
 __device__ __forceinline__ float conv1d_tile(const float* __restrict__ in, const float* __restrict__ h, int L,
-                                             long flat0, long total, float* taps, float* win) {
+                                             long flat0, long total, float* win) {
+    GAB_C1_STAMP(0);
     const int tid = threadIdx.x;
     float acc = 0.0f;
     for (int j0 = 0; j0 < L; j0 += kTapChunk) {
         const int nj = (L - j0) < kTapChunk ? (L - j0) : kTapChunk;
-        // win[kTapGroup + m] = xflat[wbase + m], m in [0, nj-1+tile); the kTapGroup floats in front
-        // of it and behind the taps are only ever prefetched, never used
+        // win[kWinPad + m] = xflat[wbase + m], m in [0, nj-1+tile); the kWinPad floats in front of it
+        // are only ever prefetched, never used
         const long wbase = flat0 - j0 - (nj - 1);
-        for (int m = tid; m < nj; m += kConvTile) taps[m] = h[j0 + m];
+        const float* const hs = h + j0;                         // wave-uniform
         for (int m = tid; m < nj - 1 + kConvTile; m += kConvTile) {
             const long g = wbase + m;
-            win[kTapGroup + m] = (g >= 0 && g < total) ? in[g] : 0.0f;   // a ragged last tile overhangs
+            win[kWinPad + m] = (g >= 0 && g < total) ? in[g] : 0.0f;   // a ragged last tile overhangs
         }
-        if (tid < kTapGroup) win[tid] = 0.0f;
+        if (tid < kWinPad) win[tid] = 0.0f;
         __syncthreads();
-        const float* w = win + kTapGroup + (nj - 1) + tid;      // w[-jj]: this output's sample at tap jj
+        GAB_C1_STAMP(1);
+        const float* w = win + kWinPad + (nj - 1) + tid;      // w[-jj]: this output's sample at tap jj
         const int valid = (int)(flat0 + tid - j0 < nj ? flat0 + tid - j0 : nj);   // START: taps 0..valid are in range
-        float xa[kTapGroup], xb[kTapGroup], ha[kTapGroup], hb[kTapGroup];
-        auto fetch = [&](float (&x)[kTapGroup], float (&hh)[kTapGroup], int at) {
-#pragma unroll
-            for (int k = 0; k < kTapGroup; ++k) { x[k] = w[-at - k]; hh[k] = taps[at + k]; }
-        };
-        auto chain = [&](const float (&x)[kTapGroup], const float (&hh)[kTapGroup], int at) {
-#pragma unroll
-            for (int k = 0; k < kTapGroup; ++k) {
-                const float next = __fadd_rn(acc, __fmul_rn(hh[k], x[k]));
-                acc = (!START || at + k <= valid) ? next : acc;     // the golden skips, it does not add zero
-            }
-        };
         int jj = 0;
-        fetch(xa, ha, 0);
-        for (; jj + 2 * kTapGroup <= nj; jj += 2 * kTapGroup) {
-            fetch(xb, hb, jj + kTapGroup);
-            chain(xa, ha, jj);
-            fetch(xa, ha, jj + 2 * kTapGroup);                  // at the end: the pads
-            chain(xb, hb, jj + kTapGroup);
+        if constexpr (!START) {
+            // every tap is in range (or meets a zero of the window: see the kernel)
+            const unsigned w_lds = (unsigned)(uintptr_t)w;          // the low half of a flat LDS address is the LDS offset
+            auto request = [&](TapGroup& g, int at) {
+                const int hat = at + kTapSet <= nj ? at : nj - kTapSet;         // past the last whole group: re-read it, unused
+                tap_group_request(g, w_lds - 4u * (unsigned)(at + kTapSet - 1), hs + hat, acc);
+            };
+            if (nj >= kTapSet) {
+                TapGroup A, B;
+                request(A, 0);
+                for (; jj + 2 * kTapSet <= nj; jj += 2 * kTapSet) {
+                    tap_group_arrive(A, acc);
+                    request(B, jj + kTapSet);
+                    acc = tap_group_chain(A, acc);
+                    tap_group_arrive(B, acc);
+                    request(A, jj + 2 * kTapSet);                       // at the end: the pads
+                    acc = tap_group_chain(B, acc);
+                }
+                tap_group_arrive(A, acc);                               // nothing stays in flight
+                if (jj + kTapSet <= nj) { acc = tap_group_chain(A, acc); jj += kTapSet; }
+            }
+            for (; jj < nj; ++jj) acc = __fadd_rn(acc, __fmul_rn(hs[jj], w[-jj]));
+        } else {
+            // the golden skips a tap that reaches before sample 0, it does not add zero: a select on the chain
+            float xa[kTapGroup], xb[kTapGroup], ha[kTapGroup], hb[kTapGroup];
+            auto fetch = [&](float (&x)[kTapGroup], float (&hh)[kTapGroup], int at) {
+#pragma unroll
+                for (int k = 0; k < kTapGroup; ++k) x[k] = w[-at - k];
+                const int hat = at + kTapGroup <= nj ? at : nj - kTapGroup;
+#pragma unroll
+                for (int k = 0; k < kTapGroup; ++k) hh[k] = hs[hat + k];
+            };
+            auto chain = [&](const float (&x)[kTapGroup], const float (&hh)[kTapGroup], int at) {
+#pragma unroll
+                for (int k = 0; k < kTapGroup; ++k) {
+                    const float next = __fadd_rn(acc, __fmul_rn(hh[k], x[k]));
+                    acc = (at + k <= valid) ? next : acc;
+                }
+            };
+            if (nj >= kTapGroup) {
+                fetch(xa, ha, 0);
+                for (; jj + 2 * kTapGroup <= nj; jj += 2 * kTapGroup) {
+                    fetch(xb, hb, jj + kTapGroup);
+                    chain(xa, ha, jj);
+                    fetch(xa, ha, jj + 2 * kTapGroup);                  // at the end: the pads
+                    chain(xb, hb, jj + kTapGroup);
+                }
+                if (jj + kTapGroup <= nj) { chain(xa, ha, jj); jj += kTapGroup; }
+            }
+            for (; jj < nj; ++jj) {
+                const float next = __fadd_rn(acc, __fmul_rn(hs[jj], w[-jj]));
+                acc = (jj <= valid) ? next : acc;
+            }
         }
-        if (jj + kTapGroup <= nj) { chain(xa, ha, jj); jj += kTapGroup; }
-        for (; jj < nj; ++jj) {
-            const float next = __fadd_rn(acc, __fmul_rn(taps[jj], w[-jj]));
-            acc = (!START || jj <= valid) ? next : acc;
-        }
+        GAB_C1_STAMP(2);
         __syncthreads();
     }
     return acc;
@@ -321,8 +430,7 @@ __global__ __launch_bounds__(kConvTile) void conv1d_direct_kernel(const float* _
                                                                  float* __restrict__ out,
                                                                  const float* __restrict__ ir,
                                                                  int L, int T, int B, int halo) {
-    __shared__ float taps[kTapChunk + 2 * kTapGroup];
-    __shared__ float win[kTapGroup + kTapChunk + kConvTile];
+    __shared__ float win[kWinPad + kTapChunk + kConvTile];
     const int t = blockIdx.y;
     const int i0 = blockIdx.x * kConvTile;
     // `in` starts `halo` tracks before the first track computed here (a channel shard's input; 0 for a whole job):
@@ -330,8 +438,20 @@ __global__ __launch_bounds__(kConvTile) void conv1d_direct_kernel(const float* _
     const long flat0 = (long)(halo + t) * B + i0;  // flat index of this tile's first output
     const long total = (long)(halo + T) * B;
     const float* h = ir + (size_t)t * L;
-    const float acc = flat0 >= L - 1 ? conv1d_tile<false>(in, h, L, flat0, total, taps, win)
-                                     : conv1d_tile<true>(in, h, L, flat0, total, taps, win);
+    // Tiles at the very start of the stream: the golden SKIPS the taps that reach before sample 0.  The window holds
+    // zeros there, a finite tap times zero is +-0, and a round-to-nearest sum that started at +0 is never -0, so adding
+    // it changes no bit: with finite taps the skip needs no code at all.  (A kernel lasts as long as its longest chain:
+    // a select on the sum here would set the duration of the whole launch.)  Only a track whose response holds an
+    // infinity or a NaN takes the chain with the select.
+    bool select_chain = false;
+    if (flat0 < L - 1) {
+        int finite = 1;
+        for (int m = threadIdx.x; m < L; m += kConvTile) finite &= (__float_as_uint(h[m]) & 0x7f800000u) != 0x7f800000u;
+        select_chain = !__syncthreads_and(finite);
+    }
+    const float acc = select_chain ? conv1d_tile<true>(in, h, L, flat0, total, win)
+                                   : conv1d_tile<false>(in, h, L, flat0, total, win);
+    GAB_C1_STAMP(3);
     if (i0 + (int)threadIdx.x < B) out[(size_t)t * B + i0 + threadIdx.x] = acc;
 }
 
@@ -671,6 +791,13 @@ int gab_iir(const float* d_in, float* d_out, const float* coeffs, float* d_state
         return gab::launch_status("iir_scan_kernel");
     });
 }
+
+#ifdef GAB_ABLATE
+int gab_debug_conv1d_stamps(unsigned long long* h_out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(gab::g_c1_stamps), sizeof(unsigned long long) * 4);
+}
+#endif
 
 int gab_conv1d_shard(const float* d_in, float* d_out, const float* d_ir, int ir_len, int tracks,
                      int bufsize, int halo_tracks, gab_stream_t stream) {

@@ -199,6 +199,38 @@ def test_conv1d_bit_exact(gab, orc, L, T, B):
         assert orc.fnv_survey(y) == "f66260025b0fa20c"           # SURVEY §8c pin, C2
 
 
+@pytest.mark.parametrize("L", [1, 15, 31, 32, 33, 63, 64, 65, 95, 96, 127, 1041, 2080])
+def test_conv1d_group_remainders_bit_exact(gab, orc, L):
+    """Every remainder of the 32-tap groups the chain is cut into, below one group, across the 1024-tap chunks, with
+    a ragged last tile (B = 300) and tiles at the start of the stream (taps that reach before sample 0)."""
+    T, B = 5, 300
+    ir = orc.conv1d_ir(L, T)
+    x = orc.noise(T * B, seed=L)
+    y = host(gab.conv1d(dev(x), dev(ir), L, T, B))
+    assert np.array_equal(bits(y), bits(orc.conv1d(x, ir, L, B, T)))
+
+
+def test_conv1d_start_of_stream_skips_taps_also_when_they_are_not_finite(gab, orc):
+    """The golden SKIPS a tap that reaches before sample 0 (cuda/bench_conv1d.cu:188-208).  With finite taps the kernel
+    lets the window's zeros do that; a response that holds an infinity or a NaN must take the chain with the select:
+    inf x 0 would be NaN where the golden has a number.  Also: signed zeros in input and taps."""
+    T, B, L = 6, 512, 300
+    ir = orc.conv1d_ir(L, T)
+    ir[0 * L + 7] = np.inf
+    ir[1 * L + 0] = np.nan
+    ir[2 * L + 299] = -np.inf
+    ir[3 * L + 11] = -0.0
+    x = orc.noise(T * B, seed=9)
+    x[::13] = -0.0
+    x[5::17] = 0.0
+    y = host(gab.conv1d(dev(x), dev(ir), L, T, B))
+    ref = orc.conv1d(x, ir, L, B, T)
+    nan_y, nan_r = np.isnan(y), np.isnan(ref)
+    assert np.array_equal(nan_y, nan_r)
+    assert np.array_equal(bits(y)[~nan_y], bits(ref)[~nan_r])
+    assert np.isfinite(ref[:7]).all()                     # the golden has numbers there: the infinite tap is skipped
+
+
 # ---------------------------------------------------------------------------
 # conv1d_accel
 # ---------------------------------------------------------------------------

@@ -10,4 +10,5 @@ $H -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o tools/ubench/bin/valu
 
 $H -O3 --offload-arch=gfx950 tools/ubench/link_duplex.hip -o tools/ubench/bin/link_duplex
 $H -O3 --offload-arch=gfx950 tools/ubench/link_modes.hip -o tools/ubench/bin/link_modes
+$H -O3 --offload-arch=gfx950 tools/ubench/dep_chain.hip -o tools/ubench/bin/dep_chain
 ls -la tools/ubench/bin
