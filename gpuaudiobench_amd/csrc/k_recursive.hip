@@ -265,8 +265,9 @@ inline IirScanConsts make_scan_consts(const BiquadCoeffs& c, int M) {
 // group of 32 taps ahead in a hand-fixed order (tap_group_*); the tiles at the
 // very start of the stream — where the golden SKIPS the taps that reach before
 // sample 0 — need no select with finite taps (see the kernel).
-// Measured (tools/stamp_conv1d.py): 29 -> 13 clocks per tap at 1024 taps
-// (one wave per SIMD), 30 -> 18 at C2 (two per SIMD, LDS-bound).
+// Measured (tools/stamp_conv1d.py): 29 -> 11.6 clocks per tap at 1024 taps
+// (one wave per SIMD: 2.3 instructions per tap at ~4.6 clocks each), 30 -> 17
+// at C2 (two per SIMD, LDS-bound).
 // ---------------------------------------------------------------------------
 #ifdef GAB_ABLATE
 // diagnostic builds: s_memtime of workgroup (1, 7), thread 0 — [0] tile entered, [1] window staged, [2] chain done, [3] back
@@ -330,16 +331,22 @@ __device__ __forceinline__ void tap_group_arrive(TapGroup& g, float& acc) {
                  :
                  : "memory");
 }
+// (products as two-wide vector multiplies: one v_pk_mul_f32 per pair of taps — one wave issues an instruction of ANY kind
+// about every 4.6 clocks, so the instruction count per tap is the chain's cost)
 __device__ __forceinline__ float tap_group_chain(const TapGroup& g, float acc) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-        acc = __fadd_rn(acc, __fmul_rn(g.h0[2 * p], g.x[p].x));
-        acc = __fadd_rn(acc, __fmul_rn(g.h0[2 * p + 1], g.x[p].y));
+        const f2v hp = {g.h0[2 * p], g.h0[2 * p + 1]};
+        const f2v pr = hp * g.x[p];
+        acc = __fadd_rn(acc, pr.x);
+        acc = __fadd_rn(acc, pr.y);
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-        acc = __fadd_rn(acc, __fmul_rn(g.h1[2 * p], g.x[8 + p].x));
-        acc = __fadd_rn(acc, __fmul_rn(g.h1[2 * p + 1], g.x[8 + p].y));
+        const f2v hp = {g.h1[2 * p], g.h1[2 * p + 1]};
+        const f2v pr = hp * g.x[8 + p];
+        acc = __fadd_rn(acc, pr.x);
+        acc = __fadd_rn(acc, pr.y);
     }
     return acc;
 }
