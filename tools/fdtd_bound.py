@@ -2,7 +2,8 @@
 
 A step cannot be shorter than the longer of
   (a) VALU issue:   counted VALU instructions per SIMD and step (rocprofv3 --pmc SQ_INSTS_VALU, tools/profile_fdtd_resident.sh)
-                    x 4 cycles per wave64 instruction / the clock the kernel ran at;
+                    x 2.63 cycles per wave64 fp32 instruction — what a SIMD with four or more waves issues, measured
+                    (tools/ubench/valu_rate: one wave alone gets one per 5.25) — / the clock the kernel ran at;
   (b) the hand-off: a block's boundary pressures of step t feed its neighbours' face rows of step t+1, so one request-to-data
                     round trip through memory sits on every step's chain — taken from the diagnostic build's clock marks (the
                     mark "quads there" of a wave that asked at the step's start, all 256 workgroups asking at once).
@@ -10,6 +11,7 @@ Also measured: the step with the hand-off ablated (diagnostic build: compute, LD
 
     python tools/fdtd_bound.py <pmc_means.json> <out.json> <out.md>      (on a GPU box; needs libgab_hip_ablate.so)
 """
+kClkPerInstr = 2.63        # a SIMD holding >= 4 waves: profiles/r04_valu_rate.txt
 import json
 import os
 import re
@@ -49,7 +51,7 @@ def main():
         # the PMC passes ran tools/fdtd_loop.py 128 334 8: 1002 steps per counted launch, 256 CUs x 4 SIMDs
         per_launch = pmc.get("counters_mean_per_launch", {}).get("SQ_INSTS_VALU")
         valu = per_launch / 1002.0 / 1024.0 if (per_launch and case == "fdtd_128") else None
-        issue_us = valu * 4 / (ghz * 1e3) if valu else None
+        issue_us = valu * kClkPerInstr / (ghz * 1e3) if valu else None
         floor = max(quads_us, issue_us or 0.0)
         out[case] = dict(grid=n, us_per_step=prod, us_per_step_diagnostic_build=diag, us_per_step_handoff_ablated=noh,
                          us_per_step_with_marks=stamped, clock_GHz=ghz,
@@ -57,7 +59,7 @@ def main():
                          valu_instructions_per_simd_per_step=valu, valu_issue_us=issue_us, floor_us_per_step=floor,
                          frac_of_floor=floor / prod)
         lines.append("| %d^3 | %.2f | %.2f / %.2f / %.2f | %s | %.2f | %.2f | %.2f | **%.2f** |" % (
-            n, prod, diag, noh, stamped, "%.2f (%.0f instr x 4 clk at %.2f GHz)" % (issue_us, valu, ghz) if issue_us else "not counted",
+            n, prod, diag, noh, stamped, "%.2f (%.0f instr x %.2f clk at %.2f GHz)" % (issue_us, valu, kClkPerInstr, ghz) if issue_us else "not counted",
             interior_us, quads_us, floor, floor / prod))
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     with open(sys.argv[3], "w") as f:

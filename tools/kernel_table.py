@@ -57,13 +57,17 @@ CASES = {
 # against what the kernel itself reads and writes, the iteration against the link.
 KERNEL_BYTES = {"modal_placeholder": 32 * 8 * 4 + 32 * 512 * 4}
 # The LDS-resident FDTD kernel moves no field through HBM: its per-step floor is the longer of (a) VALU issue — the
-# counted instructions per SIMD and step x 4 cycles per wave64 instruction at the part's clock — and (b) the neighbour
+# counted instructions per SIMD and step x 2.63 cycles per wave64 instruction (measured) at the part's clock — and (b) the neighbour
 # hand-off's request-to-data round trip with every workgroup asking at once; profiles/r04_fdtd_bound.md holds both.
 # The modal bank is VALU-bound: the golden's own phasor recurrence (unfused, so that every mode's sequence is the
-# oracle's bit for bit) is 3 packed + 2 plain fp32 instructions per mode and sample; a SIMD issues one wave64
-# instruction per 4 clocks.  Floor = modes x samples x 5 / 64 lanes / 1024 SIMDs x 4 clk / 2.4 GHz.
+# oracle's bit for bit) is 3 packed + 2 plain fp32 instructions per mode and sample.  A SIMD that holds four or more
+# waves issues a plain fp32 wave64 instruction every 2.63 clocks and a packed one every 5.2 (tools/ubench/valu_rate,
+# profiles/r04_valu_rate.txt).  Floor = modes x samples / 64 lanes / 1024 SIMDs x (3 x 5.2 + 2 x 2.63) clk / 2.4 GHz.
+MODAL_CLK_PER_WAVE_MODE_SAMPLE = 3 * 5.2 + 2 * 2.63
+
+
 def modal_bank_floor_us(n_modes, bufsize):
-    return n_modes * bufsize * 5.0 / 64 / 1024 * 4 / 2.4e3
+    return n_modes * bufsize / 64.0 / 1024 * MODAL_CLK_PER_WAVE_MODE_SAMPLE / 2.4e3
 
 
 FDTD_RESIDENT_FLOOR_US_PER_STEP = {"fdtd_128": None, "fdtd_52": None}     # filled from profiles/r04_fdtd_bound.json when present
@@ -134,7 +138,7 @@ def collect(d, out_csv, out_md):
                              # rooms resident in LDS: not an HBM figure at all — the fraction is of the kernel's own floor
                              frac_of_8TBps=(kbytes / per_iter_ns / PEAK_GBS if per_iter_ns > 0 else 0.0) if floor is None and not link and valu_floor is None else None,
                              bound=("PCIe Gen5 x16, 63 GB/s one way, %s" % meta.get("link_bound", "") if link else
-                                    "VALU issue, 5 instr per mode-sample: %.1f us" % valu_floor if valu_floor is not None else
+                                    "VALU issue, 3 packed + 2 plain fp32 per mode-sample: %.1f us" % valu_floor if valu_floor is not None else
                                     "hbm" if floor is None else "issue + neighbour hand-off, %.2f us per step" % floor),
                              frac_of_bound=(meta.get("frac_of_pcie_gen5_x16") if link else
                                             valu_floor / (per_iter_ns / 1e3) if valu_floor is not None else None if floor is None else
