@@ -55,7 +55,7 @@ __device__ __forceinline__ cf mul_by_hi(cf st, cf cs) {
 // of 5 instructions per mode-sample but half as many lanes busy: 144 vs 125 us at 2^20 modes —
 // with two or more waves per SIMD unpacked fp32 already issues at the packed rate.  Round 4: sample-outer / mode-inner
 // order, so that no instruction waits for the one before it: 112 against 113 us, the same.  What the 5-instruction
-// floor (68 us at 2.4 GHz) does not hold: the double-precision sincos per mode (~12 %), the folds (~20 %), the clock
+// floor (71 us at 2.4 GHz: tools/kernel_table.py) does not hold: the double-precision sincos per mode (~12 %), the folds (~20 %), the clock
 // under packed-fp32 load (~2.2 GHz).)
 template <int J, int TRACKS>
 __global__ __launch_bounds__(kMbThreads, 4) void modal_bank_kernel(const float* __restrict__ params,
