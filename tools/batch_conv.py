@@ -3,6 +3,7 @@ and fraction of 8 TB/s, with the batch checked bit for bit against per-buffer la
 
     python tools/batch_conv.py [channels ...]          (default: 1024 4096 16384 65536)
 """
+import os
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -10,6 +11,7 @@ import gpuaudiobench_amd as gab
 B, L = 512, 4096
 for T in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]:
     n = 64 if T <= 2048 else (16 if T <= 16384 else 8)          # buffers per launch: bounded by memory, not by the kernel
+    n = int(os.environ.get("NBUF", n))                           # NBUF=4032: one launch as long as the engine's bench leg
     alg = 4 * T * (2 * B + 2 * L)
     ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
     a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
@@ -25,7 +27,7 @@ for T in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]:
     del seq
     a.close()
     args = b.prepare_batch(x, n, y)
-    reps = max(6, 6000 // (n * max(1, T // 1024)))
+    reps = max(3 if n > 1000 else 6, 6000 // (n * max(1, T // 1024)))
     for _ in range(max(3, reps // 2)):
         b.launch_batch(args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
