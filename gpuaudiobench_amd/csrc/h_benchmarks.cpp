@@ -587,8 +587,8 @@ Conv1DAccelBenchmark::Conv1DAccelBenchmark(int ir_length, size_t buffer_size, si
       mode_(mode),
       track_offset_(track_offset),
       total_tracks_(total_tracks ? total_tracks : track_count),
-      batch_(CONV_BATCH > 1 ? CONV_BATCH : 0),
-      round_trip_(CONV_STREAMING == 2) {
+      round_trip_(CONV_STREAMING == 2),
+      batch_(CONV_BATCH > 1 ? CONV_BATCH : 0) {
     if (ir_length <= 0) throw std::invalid_argument("Conv1DAccelBenchmark: ir_length must be > 0");
     say("Conv1DAccelBenchmark: IR length = %d, FFT size = %d\n", ir_length_, fft_size_);
     ir_buffer_size = track_count * ir_length;
