@@ -438,7 +438,11 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             GAB_HIP_CHECK(hipStreamWaitEvent(s, p->copy_ev, 0));
             p->stale_lo = p->stale_hi = 0;
         }
-        if (in_size)
+        bool upload = in_size > 0;
+#ifdef GAB_ABLATE
+        if (getenv("GAB_RT_SKIP_UPLOAD")) upload = false;   // diagnostic builds: the input never lands — every wait must run out
+#endif
+        if (upload)
             GAB_HIP_CHECK(hipMemcpyAsync(p->stage, h_in, sizeof(float) * (size_t)in_size, hipMemcpyHostToDevice, p->copy_stream));
         if (in_size > out_size) {
             p->stale_lo = p->stale_hi > p->stale_lo ? std::min(p->stale_lo, out_size) : out_size;
@@ -455,7 +459,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, epoch, in_size, out_size};
         gab::datatransfer_round_trip_kernel<<<dim3(p->workgroups), dim3(gab::kBlock), 0, s>>>(rt);
         int rc = gab::launch_status("datatransfer_round_trip_kernel");
-        if (in_size) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
+        if (upload) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
         if (rc) {
             (void)hipStreamSynchronize(p->copy_stream);
             return rc;
@@ -463,8 +467,8 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         // the pinned word says the output is complete; the upload's event releases workgroups whose words really hold
         // the sentinel.  The call returns when BOTH directions are through (an input longer than the output is still
         // landing when the last output has left).
-        bool told = in_size == 0;
-        if (told) *landed = epoch;
+        bool told = !upload;                            // nothing to announce (diagnostic: nothing was uploaded, nothing is said)
+        if (in_size == 0) *landed = epoch;
         // after a wait that ran out, words may have landed behind their sentinel: the launch bounds its own waits, so let
         // it end (also before the caller may free the buffers), then start the next call from an all-sentinel stage
         auto repoison = [&]() {

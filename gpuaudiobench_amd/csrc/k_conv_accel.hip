@@ -2044,37 +2044,45 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         volatile unsigned* const done = p->rt_words;
         volatile unsigned* const landed = p->rt_words + 16;
         volatile unsigned* const error = p->rt_words + 32;
-        GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+        bool upload = true;
+#ifdef GAB_ABLATE
+        if (getenv("GAB_RT_SKIP_UPLOAD")) upload = false;   // diagnostic builds: the input never lands — every wait must run out
+#endif
+        if (upload) GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
         gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
                               epoch, p->rt_pairs_per_group, p->rt_groups};
         gab::conv_round_trip_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(rt, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
         int rc = gab::launch_status("conv_round_trip_kernel");
-        GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
+        if (upload) GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
         p->head = (p->head + 1) & (gab::kSlots - 1);
         p->fresh = false;
         if (rc) return rc;
         // the pinned word says the output is complete; the upload's event releases workgroups whose rows really
         // hold the sentinel
-        bool told = false;
+        bool told = !upload;                             // (diagnostic: nothing was uploaded, nothing is announced)
+        // After a wait that ran out, words may land behind the sentinel the kernel put back and the kernel has taken
+        // sentinels for samples: the launch bounds its own waits, so let it end (also before the caller may free the
+        // buffers), put the stage back to all-sentinel, and say that the carried history now holds garbage.
+        auto after_a_failed_wait = [&](const char* what) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(p->rt_copy_stream);
+            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, (size_t)p->tracks * p->bufsize);
+            (void)hipDeviceSynchronize();
+            *error = 0;
+            gab::set_last_error(std::string("gab_conv_round_trip: ") + what +
+                                "; the output of this call is invalid and so is the plan's carried history (gab_conv_reset before the stream goes on)");
+            return GAB_ERR_RUNTIME;
+        };
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
         while (*done != epoch) {
             if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) { *landed = epoch; told = true; }
             if ((++spins & 1023u) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
-                // the launch bounds its own waits (about a second each): let it end before the caller may free the buffers
-                (void)hipStreamSynchronize(s);
-                (void)hipStreamSynchronize(p->rt_copy_stream);
-                gab::set_last_error("gab_conv_round_trip: the launch did not report completion within 4 s; the output of this call is invalid");
-                return GAB_ERR_RUNTIME;
-            }
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0)
+                return after_a_failed_wait("the launch did not report completion within 4 s");
         }
         if (!told) *landed = epoch;
-        if (*error != 0) {
-            *error = 0;
-            gab::set_last_error("gab_conv_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
-            return GAB_ERR_RUNTIME;
-        }
+        if (*error != 0) return after_a_failed_wait("a workgroup waited about a second for its input and gave up");
         return GAB_OK;
     });
 }

@@ -217,7 +217,9 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * while later groups are still arriving (conv_round_trip_kernel).  Other plans: the kernel moves both buffers
  * over the link itself (as GAB_CONV_STREAMING_HOST_IO; h_in must then be pinned as well) and the call waits
  * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  Blocking; one call at a time
- * per plan.  GAB_ERR_RUNTIME if the input never arrived (the output of that call is then invalid).       */
+ * per plan.  GAB_ERR_RUNTIME if the input never arrived: the output of that call is then invalid AND so is the
+ * plan's carried history (the kernel took placeholders for samples) — gab_conv_reset before the stream goes on;
+ * the staging buffer has been re-armed, the next call works.                                               */
 int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
 /* ---- a resident engine fed through a doorbell (additive; split-cut plans) -----------------------------------------
  * For a caller whose buffers ARRIVE one at a time but who can keep a couple in flight: ONE launch (the batch launch's

@@ -257,6 +257,26 @@ def test_fdtd_resident_launch_that_gives_up_fails_at_that_call():
     assert "matches the oracle bit for bit: ok" in r.stdout
 
 
+def test_round_trips_whose_input_never_lands_fail_at_that_call_and_work_again():
+    """Diagnostic build (GAB_RT_SKIP_UPLOAD=1: no upload, nothing announced as landed), in a child process: the
+    bounded waits inside gab_datatransfer_round_trip's and gab_conv_round_trip's launches run out, the launches END,
+    the calls return GAB_ERR_RUNTIME; the staging buffers are re-armed: the next calls (the convolver after
+    gab_conv_reset) are right again, bit for bit (tools/round_trip_timeout_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gpuaudiobench_amd", "libgab_hip_ablate.so")
+    if not os.path.exists(lib):
+        pytest.skip("the diagnostic library is not built (GAB_BUILD_TAG=ablate GAB_ABLATE=1 python gpuaudiobench_amd/build.py)")
+    env = dict(os.environ, GAB_LIB_PATH=lib)
+    env.pop("GAB_RT_SKIP_UPLOAD", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "round_trip_timeout_check.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "datatransfer: the plan is right again: ok" in r.stdout
+    assert "conv: after the reset the plan matches device-buffer launches bit for bit: ok" in r.stdout
+
+
 def test_fdtd_wide_slab_cut_developed_field(gab, orc):
     """One >= 68-wide slab cut (rows that take the LDS-halo step kernel) run long enough for the
     front to cross the cut planes many times: 96^3, three uneven slabs, 120 samples = 360 steps,
