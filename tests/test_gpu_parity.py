@@ -598,6 +598,38 @@ def test_conv_accel_engine_feed_matches_batch_launches_and_carries_history(gab, 
     b.close()
 
 
+def test_conv_accel_engine_whose_producer_goes_away_ends_by_itself_and_says_so(gab, orc):
+    """The doorbell stops moving (the producer published three buffers and left): after about two seconds the resident
+    launch ends by itself, gab_conv_engine_stop returns GAB_ERR_RUNTIME, the device is free again, and after a reset
+    the plan convolves as a fresh one does."""
+    import time
+    import torch
+    T, B, L, R = 64, 512, 4096, 8
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    in_ring, out_ring = b.engine_rings(R)
+    in_ring.copy_(torch.cat([dev(orc.noise(T * B, seed=i)) for i in range(R)]).view(R, T * B))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    b.engine_start(R, stream=side)
+    b.engine_publish(3)
+    t0 = time.time()
+    while not side.query() and time.time() - t0 < 20.0:          # the launch must END without a stop
+        time.sleep(0.05)
+    waited = time.time() - t0
+    assert side.query(), "the engine was still running after %.1f s without a doorbell" % waited
+    assert 1.0 < waited < 15.0, waited
+    with pytest.raises(gab.GabError):
+        b.engine_stop()
+    b.reset()
+    x = dev(orc.noise(T * B, seed=77))
+    assert torch.equal(a.process(x).view(torch.int32), b.process(x).view(torch.int32))
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
                                       (4, 512, 1100, 37), (2048, 512, 4096, 3), (12, 512, 4096, 1), (36, 512, 3000, 2),
                                       (8192, 512, 4096, 2),      # C5's channel count: 2048 workgroups, eight rounds of the device
