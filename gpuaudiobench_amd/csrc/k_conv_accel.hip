@@ -904,7 +904,7 @@ constexpr int kEnginePollLimit = 1 << 21;      // x ~1 us: about two seconds wit
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // experiments only (GAB_EXTRA_FLAGS=-DGAB_ENGV=bits, a build of its own): 1 no progress words / aggregator, 2 plain output
 // stores, 4 plain input loads, 8 history from the input ring as a batch launch takes it (needs a ring of >= 9 slots),
-// 32 the doorbell is read only when the engine stalls, 64 rings in ordinary device memory.  Compile-time: a run-time switch at every load perturbs what it measures.
+// 32 the doorbell is read only when the engine stalls, 64 rings in fine-grained device memory, 256 non-temporal input loads (64 + 256: the engine as it was before the rings became ordinary memory).  Compile-time: a run-time switch at every load perturbs what it measures.
 #ifndef GAB_ENGV
 #define GAB_ENGV 0
 #endif
@@ -979,9 +979,15 @@ __device__ __forceinline__ void conv_split_resident(
     // with next_slot() instead of dividing
     auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
     auto next_slot = [&](int slot) -> int { return (ENGINE && slot + 1 == eng.ring) ? 0 : slot + 1; };
-    // the engine's input ring is rewritten while the launch runs: its loads must not be answered by a line this CU kept
+    // The engine's input ring is rewritten while the launch runs (by copy engines): its loads are system-scope loads,
+    // answered by memory and never by a line an L1 or an L2 kept.  The rings are ORDINARY device memory (round 4, measured
+    // at 1024 channels: fine-grained rings read by non-temporal loads 6.85 us per buffer, ordinary rings read by
+    // system- or agent-scope loads 6.09-6.13, by plain loads — which may be stale — 6.2-6.3).
     auto ld = [](const float* p) -> float {
-        if constexpr (ENGINE) return GAB_EABL(4) ? *p : __builtin_nontemporal_load(p);
+        if constexpr (ENGINE)
+            return GAB_EABL(4)     ? *p
+                   : GAB_EABL(256) ? __builtin_nontemporal_load(p)
+                                   : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc0 sc1
         else return *p;
     };
 
@@ -2099,8 +2105,9 @@ int gab_conv_engine_rings(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
             if (p->eng_in) { (void)hipFree(p->eng_in); p->eng_in = nullptr; }
             if (p->eng_out) { (void)hipFree(p->eng_out); p->eng_out = nullptr; }
             p->eng_ring = 0;
-            // fine-grained: what a copy or another agent writes there is seen by the running launch
-            unsigned flags = (GAB_ENGV & 64) ? hipDeviceMallocDefault : hipDeviceMallocFinegrained;   // (experiments: ordinary device memory)
+            // ordinary device memory: the launch reads the input ring with system-scope loads and writes the output
+            // ring with write-through stores, so what a copy engine writes is seen and what it reads is there
+            unsigned flags = (GAB_ENGV & 64) ? hipDeviceMallocFinegrained : hipDeviceMallocDefault;   // (experiments: fine-grained, as before)
             GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->eng_in), n * 4 * ring_buffers, flags));
             GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->eng_out), n * 4 * ring_buffers, flags));
             p->eng_ring = ring_buffers;

@@ -227,8 +227,9 @@ int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, ga
  * published it, so no kernel boundary separates buffers (conv_split_kernel: 8.9 us per buffer; the engine: the batch
  * rate).  Same state, same bits as gab_conv_process.
  *   rings     allocates (once per ring size) input / output rings of ring_buffers slots ([slot][T*B] track-major in,
- *             [slot][B*T] sample-major out; fine-grained device memory: COPY ENGINES may write and read them while the
- *             launch runs — kernels cannot: at 1024 channels the engine holds every compute unit until it stops);
+ *             [slot][B*T] sample-major out; ordinary device memory that the launch reads with system-scope loads and
+ *             writes with write-through stores: COPY ENGINES may write and read them while the launch runs — kernels
+ *             cannot: at 1024 channels the engine holds every compute unit until it stops);
  *   start     the same rings, and launches on `stream`, which the launch occupies until stop;
  *   publish   after buffer k has been written to slot k % ring_buffers: the doorbell count goes up by n_more;
  *   completed buffers whose output is complete in its slot.  The engine asks for a buffer one period before it uses it,

@@ -19,7 +19,8 @@ torch.cuda.synchronize()
 y_ref = y.clone()
 side = torch.cuda.Stream()
 import os
-for ahead in ([1000] if os.environ.get('GAB_ENGINE_ONLY_PREPUBLISHED') else [1000, 48, 32, 24, 16, 12, 8, 6]):
+for ahead in ([1000] if os.environ.get('GAB_ENGINE_ONLY_PREPUBLISHED') else
+              [int(a) for a in os.environ['ENGINE_AHEADS'].split()] if os.environ.get('ENGINE_AHEADS') else [1000, 48, 32, 24, 16, 12, 8, 6]):
     plan = gab.ConvPlan(T, B, L, scheme="split")
     plan.set_ir(ir)
     in_ring, out_ring = plan.engine_rings(R)
