@@ -449,7 +449,7 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     side = torch.cuda.Stream()
     # an untimed first launch, as `value` has its warm-up steps: the first resident launch of a process runs ~10 % slower
     # than the following ones (tools/engine_conv.py: 6.67 us per buffer, then 6.05-6.14)
-    eng_warm_passes = 4
+    eng_warm_passes = passes                          # (a 256-buffer first launch leaves 6.45 us; one of the same length 6.1)
     eplan.engine_start(NB, stream=side)
     eplan.engine_feed(eng_warm_passes * NB, ahead=ahead)
     eplan.engine_stop()
