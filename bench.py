@@ -255,7 +255,7 @@ def main():
 
     alg = algorithmic_bytes(T, B, L)
     side = {}
-    if not args.no_side_legs:
+    if not args.no_side_legs and world == 1:           # the one-GPU real-time path: reported at N = 1 only
         side = side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, args.batch_sizes)
 
     traffic, pmc = None, {}
