@@ -10,7 +10,10 @@ sys.path.insert(0, ".")
 import gpuaudiobench_amd as gab
 B, L = 512, 4096
 for T in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]:
-    n = 64 if T <= 2048 else (16 if T <= 16384 else 8)          # buffers per launch: bounded by memory, not by the kernel
+    # buffers per launch: the caller's choice (bench.py: 64).  A launch's first window, drain and boundary are paid once,
+    # so few buffers per launch cost most where a launch is several rounds of workgroups (65 536 channels: 64 rounds):
+    # 16 / 16 / 8 buffers gave 0.84 / 0.84 / 0.74 at 4 096 / 16 384 / 65 536 channels, 64 / 64 / 32 give 0.90 / 0.88 / 0.86.
+    n = 64 if T <= 16384 else 32
     n = int(os.environ.get("NBUF", n))                           # NBUF=4032: one launch as long as the engine's bench leg
     alg = 4 * T * (2 * B + 2 * L)
     ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
