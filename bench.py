@@ -5,10 +5,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the resident batch of synthetic input:
-BUFFERS_PER_STEP = 64 consecutive audio buffers (512 new samples for every one of a
+BUFFERS_PER_STEP = 128 consecutive audio buffers (512 new samples for every one of a
 rank's 1024 channels) pushed through overlap-save with carried history by ONE launch
 of gab_conv_process_batch (conv_split_batch_kernel: a workgroup owns four channels for
-the whole launch and walks the 64 buffers in order).  The inputs are resident in HBM
+the whole launch and walks the 128 buffers in order).  The inputs are resident in HBM
 before the timed region starts — the precondition the metric is quoted under — so
 nothing has to cross a kernel boundary between buffers; history carries over from one
 step to the next (the stream never restarts).  Results are bit-identical to one
@@ -21,7 +21,7 @@ independent), so scaling is weak.  A plain `python bench.py --gpus N` starts the
 ranks itself (torch.distributed.run) before touching any GPU and relays rank 0's line.
 
 One JSON line on rank 0:
-  value          = 1024-channel buffers per second, whole job (N * 64 K / max-rank time)
+  value          = 1024-channel buffers per second, whole job (N * 128 K / max-rank time)
   roofline       = algorithmic bytes per launch / average launch duration (HIP events on the
                    launch stream over the timed region), against 8 TB/s HBM
   parity_checked = after the timed region: sampled channels of the last step's first and last
@@ -46,7 +46,7 @@ TRACKS_PER_GPU = 1024
 BUFSIZE = 512
 TAPS = 4096
 FS = 48000
-BUFFERS_PER_STEP = 64           # the resident input batch (128 MiB), one launch
+BUFFERS_PER_STEP = 128          # the resident input batch (256 MiB), one launch (64: 1.5 % slower per buffer; 192: the same)
 CLOCK_WARM_STEPS = 500          # untimed, besides --warmup: ~0.2 s of the same launches; the part's clocks settle over the first ~40 ms of sustained load
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 PARITY_CHANNELS = 16            # sampled per checked buffer
@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--no-side-legs", action="store_true", help="only the timed region (profiling runs)")
     ap.add_argument("--batch-sizes", action="store_true",
                     help="also time 8 / 16 / 32 buffers per launch (off by default: those launches carry the headline "
-                         "kernel's name and would mix into a profiler's per-kernel average of the 64-buffer launches)")
+                         "kernel's name and would mix into a profiler's per-kernel average of the 128-buffer launches)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -429,23 +429,30 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     # ---- the same buffers ARRIVING one at a time at a resident launch (gab_conv_engine_*): the host rings the doorbell once
     # per buffer and keeps at most `ahead` in flight; the ring is the resident batch.  HIP events on the engine's own
     # stream around the whole launch; the output ring checked bit for bit against batch launches over the same buffers.
-    ahead, passes = 16, 63
+    ahead, passes = 16, 64
+    # The engine's ring is HALF a step (64 slots: 128 MiB in, 128 MiB out), and every batch launch of this leg — the clock
+    # warm-up, the reference — is a launch of a whole step's size over the ring's contents twice: rocprofv3's per-kernel
+    # average of the command then averages launches of ONE size (conv_split_batch_kernel: `value`'s).
+    NB_step, NB = NB, (NB // 2 if NB // 2 > ahead else NB)
+    xb_step, xb = xb, xb[:NB * T * B]
+    per = NB_step // NB                                # ring passes per reference launch (2, or 1 for a small step)
+    x2 = torch.cat([xb] * per) if per > 1 else xb
+    y2 = torch.empty_like(x2)
     ref = gab.ConvPlan(T, B, L, scheme="split")
     ref.set_ir(ir_dev)
-    yref = torch.empty_like(xb)
     eplan = gab.ConvPlan(T, B, L, scheme="split")
     eplan.set_ir(ir_dev)
     in_ring, out_ring = eplan.engine_rings(NB)
     in_ring.copy_(xb.view(NB, T * B))
-    warm = plan.prepare_batch(xb, NB, yref)           # the clocks settle over ~40 ms of sustained load: the same warm-up as `value`
-    for _ in range(300):
+    warm = plan.prepare_batch(x2, per * NB, y2)       # the clocks settle over ~40 ms of sustained load: the same warm-up as `value`
+    for _ in range(300 // per):
         plan.launch_batch(warm)
     torch.cuda.synchronize()
-    yref = None
-    for _ in range(passes):                           # (the warm-up used the buffer: the reference again)
-        yref = ref.process_batch(xb, NB, out=yref)
+    for _ in range(passes // per):                     # (the warm-up used the buffer: the reference again)
+        ref.process_batch(x2, per * NB, out=y2)
     ref.close()
     torch.cuda.synchronize()
+    yref = y2[(per - 1) * NB * T * B:]                 # what the last pass over the ring leaves
     side = torch.cuda.Stream()
     # an untimed first launch, as `value` has its warm-up steps: the first resident launch of a process runs ~10 % slower
     # than the following ones (tools/engine_conv.py: 6.67 us per buffer, then 6.05-6.14)
@@ -467,11 +474,12 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
         "entry": "gab_conv_engine_start / _feed / _stop: one resident launch (conv_split_engine_kernel), the host publishes ONE "
                  "buffer per ring of the doorbell and keeps at most %d in flight" % ahead,
         "us_per_buffer": eng_us, "buffers_per_sec": 1e6 / eng_us, "alg_GBps": alg / eng_us / 1e3,
-        "frac": alg / eng_us / 1e3 / HBM_PEAK_GBS, "buffers": passes * NB, "ahead": ahead,
+        "frac": alg / eng_us / 1e3 / HBM_PEAK_GBS, "buffers": passes * NB, "ahead": ahead, "ring_slots": NB,
         "untimed_first_launch_buffers": eng_warm_passes * NB,
         "bit_identical_to_batch_launches": bool(torch.equal(out_ring.reshape(-1).view(torch.int32), yref.view(torch.int32)))}
     eplan.close()
     plan.reset()
+    NB, xb = NB_step, xb_step
 
     # ---- batch size: how the per-launch cost (first window, drain, boundary) amortises
     sizes = {}

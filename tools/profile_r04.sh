@@ -18,7 +18,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" 
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- $BENCH > $OUT/pmc_$N.txt 2>&1
   echo "pmc $N rc=$?"
 done
-python3 tools/pmc_means.py $OUT conv_split_batch_kernel 2415919104 5 > $OUT/conv_batch_pmc_means.json; echo "pmc means rc=$?"
+python3 tools/pmc_means.py $OUT conv_split_batch_kernel 4831838208 5 > $OUT/conv_batch_pmc_means.json; echo "pmc means rc=$?"
 GAB_LIB_PATH=$PWD/gpuaudiobench_amd/libgab_hip_ablate.so python3 tools/roundtrip_timeline.py > $OUT/roundtrip_timeline.txt 2>&1; echo "timeline rc=$?"
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o roundtrip -- python3 tools/roundtrip_conv.py 1024 120 > $OUT/roundtrip_conv_traced.txt 2>&1; echo "roundtrip trace rc=$?"
 python3 tools/roundtrip_conv.py 1024 520 > $OUT/roundtrip_conv.txt 2>&1; echo "roundtrip rc=$?"
