@@ -2123,6 +2123,19 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
         if (!p || !d_in_ring || !d_out_ring) return gab::bad_arg("gab_conv_engine_start: null argument");
         if (!p->ir_set) return gab::bad_arg("gab_conv_engine_start: gab_conv_set_ir has not been called");
         if (p->eng_running) return gab::bad_arg("gab_conv_engine_start: the plan's engine is already running");
+        {
+            // Every workgroup of the engine stays on the device until the stop and waits for words other workgroups write
+            // (the relayed doorbell): all of them must be resident AT ONCE.  One fits per compute unit (151 KB of LDS).
+            int dev = 0, cus = 0, per_cu = 0;
+            GAB_HIP_CHECK(hipGetDevice(&dev));
+            GAB_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            GAB_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gab::conv_split_engine_kernel, gab::kBatchThreads, 0));
+            const long room = (long)cus * per_cu;
+            if ((long)(p->tracks / 4) > room)
+                return gab::bad_arg(("gab_conv_engine_start: the engine keeps one workgroup per four channels resident for the whole launch; this device holds " +
+                                     std::to_string(room) + " of them (" + std::to_string(4 * room) + " channels), the plan has " +
+                                     std::to_string(p->tracks) + " channels — shard the channels (one engine per device) or use gab_conv_process_batch").c_str());
+        }
         if (int rc = gab_conv_engine_rings(p, ring_buffers, d_in_ring, d_out_ring)) return rc;
         hipStream_t s = gab::as_stream(stream);
         const size_t prog_words = 2 * (size_t)(p->tracks / 4) + 32;        // + the relay word on a line of its own

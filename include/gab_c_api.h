@@ -240,7 +240,9 @@ int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, ga
  *             `ahead` (6 <= ahead < ring_buffers) in front of `completed`;
  *   stop      rings the stop bit, waits for the launch to end (every published buffer is finished), carries the
  *             history on for the next gab_conv_process / batch / engine.
- * The device is the engine's while it runs (256 workgroups at 1024 channels): other kernels queue behind it.  If the
+ * The device is the engine's while it runs (256 workgroups at 1024 channels): other kernels queue behind it, and every
+ * workgroup of the engine must be resident at once: start refuses a plan with more channels than 4 x the workgroups the
+ * device holds (1024 channels on MI355X; more channels: one engine per device over channel shards).  If the
  * doorbell does not move for about two seconds the launch ends by itself and stop / feed return GAB_ERR_RUNTIME.      */
 int gab_conv_engine_rings(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring);
 int gab_conv_engine_start(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring, gab_stream_t stream);

@@ -598,6 +598,21 @@ def test_conv_accel_engine_feed_matches_batch_launches_and_carries_history(gab, 
     b.close()
 
 
+def test_conv_accel_engine_refuses_more_channels_than_stay_resident(gab, orc):
+    """Every workgroup of the engine waits for words other workgroups write, so all of them must be on the device at
+    once: one per compute unit (four channels each).  A plan with more channels is refused at the start — it would
+    otherwise stop reporting progress and give up two seconds later."""
+    T, B, L = 2048, 512, 4096
+    plan = gab.ConvPlan(T, B, L, scheme="split")
+    plan.set_ir(dev(orc.conv_accel_ir(L, 8)).repeat(T // 8))
+    with pytest.raises(gab.GabError) as e:
+        plan.engine_start(8)
+    assert "resident" in str(e.value)
+    x = dev(orc.noise(T * B, seed=5))
+    assert host(plan.process(x)).shape == (T * B,)          # the plan itself is fine
+    plan.close()
+
+
 def test_conv_accel_engine_whose_producer_goes_away_ends_by_itself_and_says_so(gab, orc):
     """The doorbell stops moving (the producer published three buffers and left): after about two seconds the resident
     launch ends by itself, gab_conv_engine_stop returns GAB_ERR_RUNTIME, the device is free again, and after a reset
