@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void datatransfer_kernel(const float* __res
 // event has completed.  Same expression per word as datatransfer_kernel: bit-identical output.
 constexpr unsigned kLinkSentinel = 0xffa5c3e1u;
 constexpr int kLinkPollLimit = 1 << 21;            // x ~0.5 us of s_sleep: about a second, then the launch gives up
+constexpr int kLinkGrace = 128;                    // looks at a word after the host has announced the upload, before the sentinel counts as data
 constexpr int kLinkChunk = 4 * kBlock;             // words per chunk: one float4 per thread
 struct LinkRoundTrip {
     unsigned* stage;              // [>= in_size] fine-grained device memory, all sentinel between calls
@@ -202,17 +203,16 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
             __syncthreads();
             if (s_word) gave_up = true;
             __syncthreads();                                          // s_word is free for the next chunk
-            int tries = 0;
+            int tries = 0, grace = -1;
             for (;;) {
                 bool all = true;
                 for (int k = 0; k < 4; ++k)
                     if (k < n_in) { w[k] = link_peek(rt.stage + w0 + k); all = all && w[k] != kLinkSentinel; }
                 if (all || gave_up) break;
-                if ((++tries & 15) == 0 && link_peek(rt.landed) == rt.epoch) {              // landed for good: one more look
-                    for (int k = 0; k < 4; ++k)
-                        if (k < n_in) w[k] = link_peek(rt.stage + w0 + k);
-                    break;
-                }
+                // the host has seen the upload complete: a word that is STILL the sentinel is taken for a value, but only
+                // after kLinkGrace more looks (nothing rests on the completion signal never overtaking the last writes)
+                if (grace < 0 && (++tries & 15) == 0 && link_peek(rt.landed) == rt.epoch) grace = kLinkGrace;
+                if (grace >= 0 && --grace < 0) break;
                 if (tries > kLinkPollLimit) { gave_up = true; break; }
                 __builtin_amdgcn_s_sleep(10);
             }

@@ -603,6 +603,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 // Same operations in the same order as conv_overlap_save_kernel<true, true>: bit-identical to device-buffer launches.
 constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
+constexpr int kRtGrace = 128;                      // looks at a word after the host has announced the upload, before the sentinel counts as data
 struct ConvRoundTrip {
     unsigned* stage;                  // [T*B] fine-grained device memory
     float* park;                      // [B*T] device memory
@@ -695,20 +696,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     bool gave_up = s_word != 0;
     unsigned w[4];
     {
-        int tries = 0;
+        int tries = 0, grace = -1;
         for (;;) {
             w[0] = rt_peek(row + tid);
             w[1] = rt_peek(row + tid + kThreads);
             w[2] = rt_peek(row + kB + tid);
             w[3] = rt_peek(row + kB + tid + kThreads);
             if (gave_up || (w[0] != kRtSentinel && w[1] != kRtSentinel && w[2] != kRtSentinel && w[3] != kRtSentinel)) break;
-            if ((++tries & 15) == 0 && rt_peek(rt.landed) == rt.epoch) {            // landed for good: one more look, then take it
-                w[0] = rt_peek(row + tid);
-                w[1] = rt_peek(row + tid + kThreads);
-                w[2] = rt_peek(row + kB + tid);
-                w[3] = rt_peek(row + kB + tid + kThreads);
-                break;
-            }
+            // the host has seen the upload complete: a word that is STILL the sentinel is taken for a sample — but only
+            // after kRtGrace more looks (~0.1 ms), so that nothing rests on the completion signal never overtaking the
+            // engine's last writes on their way to where a shader's load finds them
+            if (grace < 0 && (++tries & 15) == 0 && rt_peek(rt.landed) == rt.epoch) grace = kRtGrace;
+            if (grace >= 0 && --grace < 0) break;
             if (tries > kRtPollLimit) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(10);
         }
