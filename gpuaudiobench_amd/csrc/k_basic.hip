@@ -442,8 +442,19 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
 #ifdef GAB_ABLATE
         if (getenv("GAB_RT_SKIP_UPLOAD")) upload = false;   // diagnostic builds: the input never lands — every wait must run out
 #endif
-        if (upload)
+        // The kernel takes a word the moment it is no longer the sentinel and puts the sentinel back: only right if the
+        // upload writes every word exactly ONCE — one engine copy from pinned (or device) memory does; what the runtime does
+        // with pageable memory is its own business: such an input is uploaded completely before the launch.
+        bool streamed = true;
+        if (upload) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, h_in) != hipSuccess || at.devicePointer == nullptr) {
+                (void)hipGetLastError();
+                streamed = false;
+            }
             GAB_HIP_CHECK(hipMemcpyAsync(p->stage, h_in, sizeof(float) * (size_t)in_size, hipMemcpyHostToDevice, p->copy_stream));
+            if (!streamed) GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
+        }
         if (in_size > out_size) {
             p->stale_lo = p->stale_hi > p->stale_lo ? std::min(p->stale_lo, out_size) : out_size;
             p->stale_hi = std::max(p->stale_hi, in_size);
@@ -459,7 +470,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, epoch, in_size, out_size};
         gab::datatransfer_round_trip_kernel<<<dim3(p->workgroups), dim3(gab::kBlock), 0, s>>>(rt);
         int rc = gab::launch_status("datatransfer_round_trip_kernel");
-        if (upload) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
+        if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
         if (rc) {
             (void)hipStreamSynchronize(p->copy_stream);
             return rc;
@@ -467,8 +478,8 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         // the pinned word says the output is complete; the upload's event releases workgroups whose words really hold
         // the sentinel.  The call returns when BOTH directions are through (an input longer than the output is still
         // landing when the last output has left).
-        bool told = !upload;                            // nothing to announce (diagnostic: nothing was uploaded, nothing is said)
-        if (in_size == 0) *landed = epoch;
+        bool told = !upload || !streamed;               // nothing to announce (diagnostic: nothing was uploaded, nothing is said)
+        if (in_size == 0 || (upload && !streamed)) *landed = epoch;
         // after a wait that ran out, words may have landed behind their sentinel: the launch bounds its own waits, so let
         // it end (also before the caller may free the buffers), then start the next call from an all-sentinel stage
         auto repoison = [&]() {

@@ -2053,18 +2053,30 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
 #ifdef GAB_ABLATE
         if (getenv("GAB_RT_SKIP_UPLOAD")) upload = false;   // diagnostic builds: the input never lands — every wait must run out
 #endif
-        if (upload) GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+        // The kernel takes a word the moment it is no longer the sentinel and puts the sentinel back: that is only right
+        // if the upload writes every word exactly ONCE — one engine copy from pinned (or device) memory does.  What the
+        // runtime does with PAGEABLE memory (staging pieces, heads and tails on their own) is its own business: such an
+        // input is uploaded completely first and announced as landed before the launch.  (profiles/r04_incident_*)
+        bool streamed = true;
+        if (upload && !mapped(h_in)) {
+            GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+            GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
+            *landed = epoch;
+            streamed = false;
+        } else if (upload) {
+            GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+        }
         gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
                               epoch, p->rt_pairs_per_group, p->rt_groups};
         gab::conv_round_trip_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(rt, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
         int rc = gab::launch_status("conv_round_trip_kernel");
-        if (upload) GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
+        if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
         p->head = (p->head + 1) & (gab::kSlots - 1);
         p->fresh = false;
         if (rc) return rc;
         // the pinned word says the output is complete; the upload's event releases workgroups whose rows really
         // hold the sentinel
-        bool told = !upload;                             // (diagnostic: nothing was uploaded, nothing is announced)
+        bool told = !upload || !streamed;               // (diagnostic: nothing was uploaded, nothing is announced)
         // After a wait that ran out, words may land behind the sentinel the kernel put back and the kernel has taken
         // sentinels for samples: the launch bounds its own waits, so let it end (also before the caller may free the
         // buffers), put the stage back to all-sentinel, and say that the carried history now holds garbage.

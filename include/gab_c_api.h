@@ -67,7 +67,8 @@ int gab_datatransfer(const float* d_in, float* d_out, int in_size, int out_size,
 
 /* The same operation with both link directions busy at once (replaces the reference's H2D -> kernel -> D2H
  * sequence around DataTransferKernel, cuda/bench_datatransfer.cu:62-75, in one call).  h_in [in_size] is any
- * host memory hipMemcpyAsync accepts (pinned for full rate); h_out [out_size] MUST be pinned (hipHostMalloc) or
+ * host memory hipMemcpyAsync accepts (pinned for the overlap; pageable memory is uploaded completely before the
+ * launch); h_out [out_size] MUST be pinned (hipHostMalloc) or
  * device memory: the kernel writes it itself while ONE engine copy of h_in lands in the plan's staging buffer.
  * Returns when h_out is complete AND the whole input has been uploaded; bit-identical to gab_datatransfer on the
  * uploaded input.  in_size <= the plan's max_in_size.  The call blocks (it is the benchmark's timed unit); `stream`
@@ -216,7 +217,9 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * at once, its history-only partition first — consumes as it lands, and the outputs go back in channel groups
  * while later groups are still arriving (conv_round_trip_kernel).  Other plans: the kernel moves both buffers
  * over the link itself (as GAB_CONV_STREAMING_HOST_IO; h_in must then be pinned as well) and the call waits
- * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  Blocking; one call at a time
+ * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  h_in: pinned for the overlap; pageable
+ * memory is accepted and uploaded completely before the launch (the kernel consumes an upload as it lands only when every
+ * word is written exactly once, which one engine copy from pinned memory does).  Blocking; one call at a time
  * per plan.  GAB_ERR_RUNTIME if the input never arrived: the output of that call is then invalid AND so is the
  * plan's carried history (the kernel took placeholders for samples) — gab_conv_reset before the stream goes on;
  * the staging buffer has been re-armed, the next call works.                                               */
