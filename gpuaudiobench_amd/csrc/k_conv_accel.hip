@@ -2058,7 +2058,11 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         // runtime does with PAGEABLE memory (staging pieces, heads and tails on their own) is its own business: such an
         // input is uploaded completely first and announced as landed before the launch.  (profiles/r04_incident_*)
         bool streamed = true;
-        if (upload && !mapped(h_in)) {
+        bool may_stream_pageable = false;
+#ifdef GAB_ABLATE
+        if (getenv("GAB_RT_STREAM_PAGEABLE")) may_stream_pageable = true;      // diagnostic builds: the form the incident was met with
+#endif
+        if (upload && !may_stream_pageable && !mapped(h_in)) {
             GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
             GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
             *landed = epoch;
@@ -2290,6 +2294,22 @@ int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* histor
 }
 
 #ifdef GAB_ABLATE
+// diagnostic builds only: how many words of the round trip's staging buffer are NOT the sentinel (between calls: none)
+int gab_debug_rt_stage_dirty(gab_conv_plan* p, long long* first_index) {
+    if (!p || !p->rt_stage) return -1;
+    (void)hipDeviceSynchronize();
+    const size_t n = (size_t)p->tracks * p->bufsize;
+    std::vector<unsigned> h(n);
+    if (hipMemcpy(h.data(), p->rt_stage, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int dirty = 0;
+    if (first_index) *first_index = -1;
+    for (size_t i = 0; i < n; ++i)
+        if (h[i] != gab::kRtSentinel) {
+            if (!dirty && first_index) *first_index = (long long)i;
+            ++dirty;
+        }
+    return dirty;
+}
 // diagnostic builds only: arm (mins to ~0ull, maxes to 0) / read the round-trip kernel's per-group stamps
 int gab_debug_rt_stamps(unsigned long long* h_out, int arm) {
     (void)hipDeviceSynchronize();
