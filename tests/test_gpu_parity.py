@@ -231,6 +231,19 @@ def test_conv1d_start_of_stream_skips_taps_also_when_they_are_not_finite(gab, or
     assert np.isfinite(ref[:7]).all()                     # the golden has numbers there: the infinite tap is skipped
 
 
+def where_bits_differ(a, b, T):
+    """'' when the two sample-major [B][T] outputs are the same bits; else WHERE they differ (for an assertion message: a
+    mismatch that cannot be made to happen again should at least say which rows and channels it was)."""
+    d = bits(a) != bits(b)
+    if not d.any():
+        return ""
+    idx = np.flatnonzero(d)
+    smp, ch = idx // T, idx % T
+    return ("%d words differ: samples %d..%d (%d distinct), channels %d..%d (%d distinct); NaN in a: %d, in b: %d; first at %d: %r vs %r"
+            % (idx.size, smp.min(), smp.max(), np.unique(smp).size, ch.min(), ch.max(), np.unique(ch).size,
+               int(np.isnan(np.asarray(a)).sum()), int(np.isnan(np.asarray(b)).sum()), idx[0], np.asarray(a).ravel()[idx[0]], np.asarray(b).ravel()[idx[0]]))
+
+
 # ---------------------------------------------------------------------------
 # conv1d_accel
 # ---------------------------------------------------------------------------
@@ -449,7 +462,7 @@ def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, 
             yb = host(b.process(dev(x), mode=gab.CONV_STREAMING))
         else:
             yb = b.round_trip(h_in, h_out).numpy().copy()     # complete when the call returns: no synchronize here
-        assert np.array_equal(bits(ya), bits(yb)), "buffer %d" % i
+        assert not where_bits_differ(ya, yb, T), "buffer %d: %s" % (i, where_bits_differ(ya, yb, T))
         if T <= 64:
             ref = orc.conv_accel_stream(x, ir_h, hist, L, B, T, f64=True)
             worst, peak = max(worst, float(np.abs(yb - ref).max())), max(peak, float(np.abs(ref).max()))
@@ -458,13 +471,15 @@ def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, 
     # a pageable input: every group comes by the engine copy (a pinned one lets the kernel read the first group itself)
     x = orc.noise(T * B, seed=8)
     ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
-    assert np.array_equal(bits(ya), bits(b.round_trip(torch.from_numpy(x.copy()), h_out).numpy()))
+    yb = b.round_trip(torch.from_numpy(x.copy()), h_out).numpy().copy()
+    assert not where_bits_differ(ya, yb, T), "pageable input: %s" % where_bits_differ(ya, yb, T)
     # the staging buffer is re-armed after every buffer: the same input twice in a row is two buffers, not one
     x = orc.noise(T * B, seed=7)
     h_in.copy_(torch.from_numpy(x))
-    for _ in range(2):
+    for k in range(2):
         ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
-        assert np.array_equal(bits(ya), bits(b.round_trip(h_in, h_out).numpy()))
+        yb = b.round_trip(h_in, h_out).numpy().copy()
+        assert not where_bits_differ(ya, yb, T), "same input, call %d: %s" % (k, where_bits_differ(ya, yb, T))
     a.close()
     b.close()
 
