@@ -2104,6 +2104,11 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         }
         if (!told) *landed = epoch;
         if (*error != 0) return after_a_failed_wait("a workgroup waited about a second for its input and gave up");
+        // The completion word rests on a store to pinned memory counting as ordered once its wave's vmcnt has drained, for
+        // the rows of OTHER compute units too.  From 8 MiB of output on (8192 channels: a 0.65 ms call) the call also
+        // waits for the launch itself to end — a few microseconds, under 1 % there; the 2 MiB real-time case keeps the
+        // word alone.  (profiles/r04_incident_roundtrip_8192_mismatch.txt: cause not established.)
+        if (bytes >= (size_t(8) << 20)) GAB_HIP_CHECK(hipStreamSynchronize(s));
         return GAB_OK;
     });
 }
