@@ -351,6 +351,13 @@ def main():
     if parity is not None and not parity["ok"]:
         sys.stderr.write("bench.py: PARITY CHECK FAILED: %s\n" % json.dumps(parity))
         return 1
+    # the side legs compare their outputs bit for bit with the launches `value` is measured on: a False there is a wrong
+    # result on the real-time path, not a footnote
+    wrong = [leg + "." + k for leg in ("round_trip", "one_buffer_per_doorbell") for k, v in (side.get(leg) or {}).items()
+             if k.startswith("bit_identical") and v is False]
+    if wrong:
+        sys.stderr.write("bench.py: BIT-IDENTITY CHECK FAILED: %s\n" % ", ".join(wrong))
+        return 1
     return 0
 
 

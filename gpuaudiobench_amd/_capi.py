@@ -102,9 +102,12 @@ PROTOTYPES = {
     "gab_conv_get_scheme": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_process_batch": (_I, [_P, _P, _P, _I, _P]),
     "gab_conv_round_trip": (_I, [_P, _P, _P, _P]),
+    "gab_conv_newest_block": (_I, [_P, _P, _P]),
     "gab_conv_engine_rings": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P)]),
     "gab_conv_engine_start": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _P]),
     "gab_conv_engine_publish": (_I, [_P, _I]),
+    "gab_conv_engine_submit": (_I, [_P, _I, _I]),
+    "gab_conv_engine_wait": (_I, [_P, _I, C.c_double]),
     "gab_conv_engine_completed": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_engine_feed": (_I, [_P, _I, _I]),
     "gab_conv_engine_stop": (_I, [_P]),

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("GAB_CSRC") or os.path.join(HERE, "csrc")      # (GAB_CSRC: an A/B build from another copy of the sources)
 # GAB_BUILD_TAG=<tag>: a diagnostic build beside the product one (libgab_hip_<tag>.so, own object
 # directory); load it with GAB_LIB_PATH.  The product library is always libgab_hip.so.
 _TAG = os.environ.get("GAB_BUILD_TAG", "")

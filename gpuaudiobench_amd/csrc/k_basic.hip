@@ -3,6 +3,7 @@
 // stride-B (uncoalesced) access pattern (cuda/bench_gain.cu:6-24 etc.); here
 // every kernel is element- or wave-parallel with 16-byte coalesced accesses.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -157,13 +158,12 @@ __global__ __launch_bounds__(kBlock) void datatransfer_kernel(const float* __res
 // event has completed.  Same expression per word as datatransfer_kernel: bit-identical output.
 constexpr unsigned kLinkSentinel = 0xffa5c3e1u;
 constexpr int kLinkPollLimit = 1 << 21;            // x ~0.5 us of s_sleep: about a second, then the launch gives up
-constexpr int kLinkGrace = 128;                    // looks at a word after the host has announced the upload, before the sentinel counts as data
 constexpr int kLinkChunk = 4 * kBlock;             // words per chunk: one float4 per thread
 struct LinkRoundTrip {
     unsigned* stage;              // [>= in_size] fine-grained device memory, all sentinel between calls
     float* h_out;                 // [out_size] pinned host memory
     unsigned* counter;            // device: workgroups finished, runs on from call to call
-    unsigned* done;               // pinned host: the epoch, once h_out is complete
+    unsigned* done;               // pinned host: the epoch, once every workgroup has finished (a HINT: the call waits for the launch's end)
     const unsigned* landed;       // pinned host: the epoch, once the host has seen the upload complete
     unsigned* error;              // pinned host: nonzero if a wait ran out
     unsigned epoch;
@@ -203,16 +203,19 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
             __syncthreads();
             if (s_word) gave_up = true;
             __syncthreads();                                          // s_word is free for the next chunk
-            int tries = 0, grace = -1;
+            int tries = 0;
             for (;;) {
                 bool all = true;
                 for (int k = 0; k < 4; ++k)
                     if (k < n_in) { w[k] = link_peek(rt.stage + w0 + k); all = all && w[k] != kLinkSentinel; }
                 if (all || gave_up) break;
-                // the host has seen the upload complete: a word that is STILL the sentinel is taken for a value, but only
-                // after kLinkGrace more looks (nothing rests on the completion signal never overtaking the last writes)
-                if (grace < 0 && (++tries & 15) == 0 && link_peek(rt.landed) == rt.epoch) grace = kLinkGrace;
-                if (grace >= 0 && --grace < 0) break;
+                // a word that is STILL the sentinel is a value only behind an acquire of `landed` (released by the host
+                // after the copy's completion event): one more look after the acquire is final
+                if ((++tries & 15) == 0 && __hip_atomic_load(rt.landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == rt.epoch) {
+                    for (int k = 0; k < 4; ++k)
+                        if (k < n_in) w[k] = link_peek(rt.stage + w0 + k);
+                    break;
+                }
                 if (tries > kLinkPollLimit) { gave_up = true; break; }
                 __builtin_amdgcn_s_sleep(10);
             }
@@ -234,8 +237,8 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
                 if (w0 + k < rt.out_size) __hip_atomic_store(dst + k, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    // every wave waits until the link's ordered queue has accepted its rows, THEN the workgroup counts as finished:
-    // the workgroup whose count completes the launch issues the completion word behind every row
+    // every wave waits for its rows, then the workgroup counts as finished; the one whose count completes the launch
+    // writes the hint word (the host then waits for the launch's END: completion is the stream's, not this word's)
     if (gave_up) __hip_atomic_store(rt.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -367,6 +370,7 @@ struct gab_link_plan {
     unsigned* words = nullptr;        // pinned: [0] done, [16] landed, [32] error
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev = nullptr;
+    hipEvent_t done_ev = nullptr;      // the launch's own completion (hipExtLaunchKernelGGL's stop event)
     unsigned epoch = 0;
     const void* checked_out = nullptr;
     // input words an earlier call uploaded but did not consume (its input was longer than its output): they hold
@@ -377,6 +381,7 @@ struct gab_link_plan {
         if (counter) (void)hipFree(counter);
         if (words) (void)hipHostFree(words);
         if (copy_ev) (void)hipEventDestroy(copy_ev);
+        if (done_ev) (void)hipEventDestroy(done_ev);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
@@ -397,6 +402,7 @@ int gab_link_plan_create(int max_in_size, gab_link_plan** out) {
         for (int i = 0; i < 64; ++i) p->words[i] = 0;
         GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
         GAB_HIP_CHECK(hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming));
+        GAB_HIP_CHECK(hipEventCreateWithFlags(&p->done_ev, hipEventDisableTiming));
 #ifdef GAB_ABLATE
         if (getenv("GAB_LINK_WGS")) p->workgroups = std::max(1, atoi(getenv("GAB_LINK_WGS")));
 #endif
@@ -463,25 +469,17 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
             return GAB_OK;
         }
-        const unsigned epoch = ++p->epoch;
+        const unsigned epoch = p->epoch + 1;            // moves only when a launch has really been made (the device counter runs on)
         volatile unsigned* const done = p->words;
-        volatile unsigned* const landed = p->words + 16;
+        unsigned* const landed = p->words + 16;
         volatile unsigned* const error = p->words + 32;
         gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, epoch, in_size, out_size};
-        gab::datatransfer_round_trip_kernel<<<dim3(p->workgroups), dim3(gab::kBlock), 0, s>>>(rt);
+        // the launch carries its own stop event: what the call returns on (k_conv_accel.hip, kRtCompletion: the cheapest of
+        // the stated ways to learn that a launch has ended, profiles/r05_roundtrip_completion.txt)
+        hipExtLaunchKernelGGL(gab::datatransfer_round_trip_kernel, dim3(p->workgroups), dim3(gab::kBlock), 0, s, nullptr, p->done_ev, 0, rt);
         int rc = gab::launch_status("datatransfer_round_trip_kernel");
-        if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
-        if (rc) {
-            (void)hipStreamSynchronize(p->copy_stream);
-            return rc;
-        }
-        // the pinned word says the output is complete; the upload's event releases workgroups whose words really hold
-        // the sentinel.  The call returns when BOTH directions are through (an input longer than the output is still
-        // landing when the last output has left).
-        bool told = !upload || !streamed;               // nothing to announce (diagnostic: nothing was uploaded, nothing is said)
-        if (in_size == 0 || (upload && !streamed)) *landed = epoch;
-        // after a wait that ran out, words may have landed behind their sentinel: the launch bounds its own waits, so let
-        // it end (also before the caller may free the buffers), then start the next call from an all-sentinel stage
+        // after a wait that ran out (or a launch that was not made), words may sit in the stage without a consumer: the
+        // launch bounds its own waits, so let it end, then start the next call from an all-sentinel stage
         auto repoison = [&]() {
             (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(p->copy_stream);
@@ -489,18 +487,49 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             (void)hipDeviceSynchronize();
             p->stale_lo = p->stale_hi = 0;
         };
+        if (rc) {
+            if (upload) repoison();
+            return rc;
+        }
+        p->epoch = epoch;
+        if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
+        // The upload's event releases workgroups whose words really hold the sentinel (`landed`: a release store the kernel
+        // acquires); the hint word says when the launch is about to end; the call returns when the launch HAS ended
+        // (its stop event) and the upload is through (an input longer than the output is still landing when the last
+        // output has left) — the same completion rule as gab_conv_round_trip, see k_conv_accel.hip.
+        bool told = !upload || !streamed;               // nothing to announce (diagnostic: nothing was uploaded, nothing is said)
+        if (in_size == 0 || (upload && !streamed)) __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
+        bool ended = false;
         while (*done != epoch || !told) {
-            if (!told && hipEventQuery(p->copy_ev) == hipSuccess) { *landed = epoch; told = true; }
-            if ((++spins & 1023u) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
-                repoison();
-                gab::set_last_error("gab_datatransfer_round_trip: the launch did not report completion within 4 s; the output of this call is invalid");
-                return GAB_ERR_RUNTIME;
+            if (!told && hipEventQuery(p->copy_ev) == hipSuccess) { __atomic_store_n(landed, epoch, __ATOMIC_RELEASE); told = true; }
+            if ((++spins & 1023u) == 0) {
+                if (told && hipStreamQuery(s) == hipSuccess) { ended = true; break; }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+                    repoison();
+                    gab::set_last_error("gab_datatransfer_round_trip: the launch did not end within 4 s; the output of this call is invalid");
+                    return GAB_ERR_RUNTIME;
+                }
             }
         }
-        if (*error != 0) {
+        (void)hipGetLastError();
+        if (ended) {
+            GAB_HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+            for (spins = 0;;) {
+                const hipError_t q = hipEventQuery(p->done_ev);
+                if (q == hipSuccess) break;
+                (void)hipGetLastError();
+                if (q != hipErrorNotReady) GAB_HIP_CHECK(q);
+                if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+                    repoison();
+                    gab::set_last_error("gab_datatransfer_round_trip: the launch did not end within 4 s; the output of this call is invalid");
+                    return GAB_ERR_RUNTIME;
+                }
+            }
+        }
+        if (*error != 0 || *done != epoch) {
             *error = 0;
             repoison();
             gab::set_last_error("gab_datatransfer_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");

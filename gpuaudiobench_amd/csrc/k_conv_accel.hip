@@ -31,6 +31,7 @@
 // conv_split_kernel below ("split roles"): taps [0,512) + [512,1024) on one
 // workgroup, taps [1024,4096) every other buffer and one buffer ahead on another.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -599,17 +600,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 //   down  outputs are parked sample-major in device memory by write-through stores; the workgroup whose arrival
 //         completes a channel group (the copy lands groups in order) drains the group's slab to the pinned output in
 //         whole rows of the group's width, so the link carries 256-512-byte pieces while later groups are still landing;
-//   done  the drain that completes the last group writes the epoch to a pinned word the host is spinning on.
+//   done  the call returns when the LAUNCH HAS ENDED (hipStreamSynchronize on the caller's stream).  The drain that
+//         completes the last group also writes the epoch to a pinned word: a hint that tells the spinning host when to go
+//         and wait for the stream, nothing more.
+// What each hand-off rests on (round 5; profiles/r05_roundtrip_protocol.md has the reasoning and the record it answers):
+//   upload -> kernel   a naturally aligned 32-bit word is single-copy atomic (HSA), so a word read as "not the sentinel" is
+//         the input word — given that the copy writes every word ONCE with its final value (one linear engine copy from
+//         pinned memory; inputs that are not pinned are uploaded completely before the launch).  That is the one
+//         assumption the overlap needs and it is checkable after the fact: the consumed block is the plan's newest
+//         history block (gab_conv_newest_block; tests and tools/roundtrip_stress.py compare it with h_in).  A word
+//         that really IS the sentinel is accepted only behind an acquire of `landed`, which the host releases after it has
+//         seen the copy's completion event (HSA: a completed copy's writes are visible at system scope).
+//   re-arm -> next upload   the sentinel stores belong to a launch that has ended before the call returns, and the next
+//         call's copy is submitted after that: ordered by the stream synchronisation, not by a counter.
+//   rows -> host   the rows are the launch's stores to pinned memory; the host reads them after the launch's completion
+//         signal (HIP: everything a kernel wrote is visible to the host once its stream has been synchronised).
 // Same operations in the same order as conv_overlap_save_kernel<true, true>: bit-identical to device-buffer launches.
 constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
+constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
-constexpr int kRtGrace = 128;                      // looks at a word after the host has announced the upload, before the sentinel counts as data
 struct ConvRoundTrip {
     unsigned* stage;                  // [T*B] fine-grained device memory
     float* park;                      // [B*T] device memory
     float* h_out;                     // [B*T] pinned host memory
     unsigned* counters;               // device: [32 g + {0,1,2}] arrivals / claims / announced epoch of group g, [32 groups] shares drained
-    unsigned* done;                   // pinned host: the epoch, once h_out is complete
+    unsigned* done;                   // pinned host: the epoch, once the last share has been drained (a HINT: the call waits for the launch's end)
     const unsigned* landed;           // pinned host: the epoch, once the host has seen the upload complete
     unsigned* error;                  // pinned host: nonzero if a wait ran out
     unsigned epoch;
@@ -696,18 +711,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     bool gave_up = s_word != 0;
     unsigned w[4];
     {
-        int tries = 0, grace = -1;
+        int tries = 0;
         for (;;) {
             w[0] = rt_peek(row + tid);
             w[1] = rt_peek(row + tid + kThreads);
             w[2] = rt_peek(row + kB + tid);
             w[3] = rt_peek(row + kB + tid + kThreads);
             if (gave_up || (w[0] != kRtSentinel && w[1] != kRtSentinel && w[2] != kRtSentinel && w[3] != kRtSentinel)) break;
-            // the host has seen the upload complete: a word that is STILL the sentinel is taken for a sample — but only
-            // after kRtGrace more looks (~0.1 ms), so that nothing rests on the completion signal never overtaking the
-            // engine's last writes on their way to where a shader's load finds them
-            if (grace < 0 && (++tries & 15) == 0 && rt_peek(rt.landed) == rt.epoch) grace = kRtGrace;
-            if (grace >= 0 && --grace < 0) break;
+            // A word that is STILL the sentinel counts as a sample only on this chain: the copy's completion signal (its
+            // writes are visible at system scope before it: HSA) -> the host's hipEventQuery -> the host's release store
+            // to `landed` -> THIS acquire load -> loads issued after it.  One more look behind the acquire is final.
+            if ((++tries & 15) == 0 && __hip_atomic_load(rt.landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == rt.epoch) {
+                w[0] = rt_peek(row + tid);
+                w[1] = rt_peek(row + tid + kThreads);
+                w[2] = rt_peek(row + kB + tid);
+                w[3] = rt_peek(row + kB + tid + kThreads);
+                break;
+            }
             if (tries > kRtPollLimit) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(10);
         }
@@ -802,8 +822,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
         ++drained;
         if (role != 2) break;                                    // helpers take one share; the last arriver takes what is left
     }
-    // every wave waits for its own rows to be accepted by the link's ordered queue, THEN its shares count as drained; the
-    // workgroup whose count completes the launch therefore issues the completion word behind every row of every group
+    // every wave waits for its own rows, then its shares count as drained; the workgroup whose count completes the launch
+    // writes the hint word (the host goes and waits for the launch's end when it sees it: completion is the stream's)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     GAB_RT_STAMP_MAX(g, 3);
@@ -909,11 +929,18 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #endif
 #define GAB_EABL(bit) ((GAB_ENGV & (bit)) != 0)
 
-template <bool ENGINE>
-__device__ __forceinline__ void conv_split_resident(
+// ---- n buffers per launch (gab_conv_process_batch; bench.py's `value`) --------------------------------------------------
+// Round 5: the batch launch has this function to itself again.  Round 4 ran batch launch and engine from one template;
+// when the engine's period loop was wrapped in a loop over bursts (one buffer in flight, below), the SAME period code
+// compiled to a different schedule for the batch instantiation too and ran 1.0-1.4 % slower (5.10 -> 5.17 us per buffer,
+// same box, three alternations: profiles/r05_batch_ab.txt).  The text below is round 4's with the engine's branches taken
+// out: the compiler's output for conv_split_batch_kernel is instruction for instruction what it was.
+__device__ __forceinline__ void conv_split_batch_resident(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0, int n_buffers,
-    const ConvEngine& eng, cf* __restrict__ lds, unsigned* __restrict__ s_door) {
+    cf* __restrict__ lds) {
+    constexpr bool ENGINE = false;                                    // (for GAB_BSTAMP's period choice in diagnostic builds)
+    (void)ENGINE;
     cf* const far_x = lds + 6 * kWaveImg;
     cf* const far_y = far_x + kLdsHalf;
     cf* const carry = far_y + kLdsHalf;                               // [pair of the duo][slot][512]
@@ -922,73 +949,15 @@ __device__ __forceinline__ void conv_split_resident(
     const size_t step = (size_t)T * kB;
     cf* const carry_g = sp.carry + (size_t)(2 * d) * kCarrySlots * kB;   // the duo's two rings are contiguous
     for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry[i] = carry_g[i];
-    constexpr int kPoller = 2 * 64;                                   // lane 0 of the first inverse wave
-    // the doorbell as this workgroup may read it: workgroup 0 asks the host and passes the answer on, the others ask the relay
-    auto read_door = [&]() -> unsigned {
-        if (blockIdx.x == 0) {
-            const unsigned v = __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(eng.relay, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return v;
-        }
-        return __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    if constexpr (ENGINE) {
-        if (tid == kPoller) s_door[0] = read_door();
-    }
     __syncthreads();
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
-    // How many buffers may be touched, asked by EVERY wave at the top of period nb (same answer in all of them: it is
-    // read from LDS, written before the previous period's closing barrier).  Batch launches: n_buffers.
-    auto gate = [&](int nb) -> int {
-        if constexpr (!ENGINE) {
-            return n_buffers;
-        } else {
-            for (;;) {
-                // (the same word in every lane: said so, or every test on it becomes an exec-masked region — the far
-                // role's request burst under a divergent branch took 2.4 instead of 1.4 us of its barrier interval)
-                const unsigned D = __builtin_amdgcn_readfirstlane(s_door[nb & 1]);
-                const int pub = (int)(D & 0x7fffffffu);
-                const bool stop = (D >> 31) != 0;
-                if (pub >= nb + 2 || (stop && pub >= nb + 1)) return pub;
-                if (stop) return nb;                                  // nothing more will come
-                __syncthreads();                                      // every wave has read the word
-                if (tid == kPoller) {
-                    unsigned v = D;
-                    int tries = 0;
-                    for (;;) {
-                        v = read_door();
-                        const int p2 = (int)(v & 0x7fffffffu);
-                        if (p2 >= nb + 2 || (v >> 31)) break;
-                        if (++tries > kEnginePollLimit) {             // the producer is gone: stop here, say so
-                            __hip_atomic_store(eng.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            v = 0x80000000u | (unsigned)(p2 < nb ? p2 : nb);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(20);
-                    }
-                    s_door[nb & 1] = v;
-                }
-                __syncthreads();
-            }
-        }
-    };
-    // buffer nb lives in slot nb % ring of the engine's rings (a batch launch: buffer nb itself); callers walk the slots
-    // with next_slot() instead of dividing
+    auto gate = [&](int) -> int { return n_buffers; };    // (the engine's doorbell gate stands here in conv_split_engine_resident)
+    // buffer nb of the launch; callers walk the buffers with next_slot()
     auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
-    auto next_slot = [&](int slot) -> int { return (ENGINE && slot + 1 == eng.ring) ? 0 : slot + 1; };
-    // The engine's input ring is rewritten while the launch runs (by copy engines): its loads are system-scope loads,
-    // answered by memory and never by a line an L1 or an L2 kept.  The rings are ORDINARY device memory (round 4, measured
-    // at 1024 channels: fine-grained rings read by non-temporal loads 6.85 us per buffer, ordinary rings read by
-    // system- or agent-scope loads 6.09-6.13, by plain loads — which may be stale — 6.2-6.3).
-    auto ld = [](const float* p) -> float {
-        if constexpr (ENGINE)
-            return GAB_EABL(4)     ? *p
-                   : GAB_EABL(256) ? __builtin_nontemporal_load(p)
-                                   : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc0 sc1
-        else return *p;
-    };
+    auto next_slot = [&](int slot) -> int { return slot + 1; };
+    auto ld = [](const float* p) -> float { return *p; };
 
     if (w >= 4) {
         // ---- far waves: F of the pair whose turn it is (window = blocks k-7 .. k; the two newest straight from
@@ -1016,24 +985,10 @@ __device__ __forceinline__ void conv_split_resident(
             const float* const cur = in_slot(slot);
             z[14] = mk(ld(cur + ca + ft), ld(cur + cb_ + ft));
             z[15] = mk(ld(cur + ca + ft + kThreads), ld(cur + cb_ + ft + kThreads));
-            if constexpr (ENGINE && !GAB_EABL(8)) {                   // k-1 from the input ring, the rest from the history ring
-                if constexpr (!FIRST) {
-                    const float* const prv = in_slot(slot_before);
-                    z[12] = mk(ld(prv + ca + ft), ld(prv + cb_ + ft));
-                    z[13] = mk(ld(prv + ca + ft + kThreads), ld(prv + cb_ + ft + kThreads));
-                } else {
-                    const int s = ((head + kSlots - 1) & (kSlots - 1)) * kB;
-                    z[12] = hp[s + ft];
-                    z[13] = hp[s + kThreads + ft];
-                }
-#pragma unroll
-                for (int r = 0; r < 12; ++r)
-                    z[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
-            } else if (nb >= kSlots - 1) {                            // the whole window lies inside the launch
+            if (nb >= kSlots - 1) {                                   // the whole window lies inside the launch
 #pragma unroll
                 for (int bl = 0; bl < 7; ++bl) {
-                    int sb = slot - (7 - bl);                         // (engine experiments: the ring wraps)
-                    if (ENGINE && sb < 0) sb += eng.ring;
+                    const int sb = slot - (7 - bl);
                     const float* const src = in_slot(sb);
                     z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
                     z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
@@ -1174,7 +1129,7 @@ __device__ __forceinline__ void conv_split_resident(
             __syncthreads();                                          // barrier 1
 #pragma unroll
             for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
-            if ((ENGINE && !GAB_EABL(8)) || nb + kSlots >= n_buffers) {   // the ring only has to hold the launch's LAST eight blocks
+            if (nb + kSlots >= n_buffers) {                              // the ring only has to hold the launch's LAST eight blocks
 #pragma unroll
                 for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];
             }
@@ -1229,50 +1184,11 @@ __device__ __forceinline__ void conv_split_resident(
         using WFi = fft::WaveFFT1024<true>;
         WFi::Lean t;
         WFi::load_twiddles(t, tw, lane);
-        int oslot = 0;                                                // of buffer nb - 1, from period 1 on
         for (int nb = 0;; ++nb) {
             const int avail = gate(nb);
             const bool more = nb < avail;                             // the other roles work on buffer nb in this period
-            unsigned door_next = s_door[nb & 1];                      // (no per-period poll: the word as last seen)
-            u4 prog_a = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, prog_b = prog_a;
-            if constexpr (ENGINE) {
-                if (nb >= 2 && !GAB_EABL(1)) {
-                    // this wave's rows of buffer nb - 2 were stored a period ago: drained by now, so the wait is free,
-                    // and the count of finished buffers can go out (write-through, nobody waits for it)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)(nb - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (tid == kPoller && eng.poll_every_period)          // asked now, needed at the period's end
-                    door_next = blockIdx.x == 0 ? __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                                : __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) {     // the aggregator: every wave's count, 8 per lane
-                    const auto srd = __builtin_amdgcn_make_buffer_rsrc(eng.progress, 0, (int)(8u * gridDim.x), 0x00020000);
-                    prog_a = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane, 0, 16);          // sc1; beyond the end: zeros dropped below
-                    prog_b = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane + 16u, 0, 16);
-                }
-            }
-            auto close_period = [&]() {                               // before the closing barrier
-                if constexpr (ENGINE) {
-                    if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) {
-                        const unsigned words = 2u * gridDim.x;        // lanes beyond the array read zeros: mask them out
-                        auto pick = [&](unsigned v, unsigned idx) { return idx < words ? v : 0xffffffffu; };
-                        unsigned m = min(min(min(pick(prog_a[0], 8u * lane), pick(prog_a[1], 8u * lane + 1)), min(pick(prog_a[2], 8u * lane + 2), pick(prog_a[3], 8u * lane + 3))),
-                                         min(min(pick(prog_b[0], 8u * lane + 4), pick(prog_b[1], 8u * lane + 5)), min(pick(prog_b[2], 8u * lane + 6), pick(prog_b[3], 8u * lane + 7))));
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
-                        if (lane == 0) __hip_atomic_store(eng.completed, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                    if (tid == kPoller) {
-                        s_door[(nb + 1) & 1] = door_next;
-                        if (blockIdx.x == 0 && eng.poll_every_period)
-                            __hip_atomic_store(eng.relay, door_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            };
             if (nb == 0) {                                            // first period: nothing to turn yet
-                for (int i = 0; i < kBatchBarriers - 1; ++i) __syncthreads();
-                close_period();
-                __syncthreads();
+                for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
                 if (!more) break;
                 continue;
             }
@@ -1286,8 +1202,7 @@ __device__ __forceinline__ void conv_split_resident(
             // One piece per barrier interval: hand-over read | pass 0 | pass 1 | pass 2 + far share | swap | stores
             const int b = nb - 1;                                     // the buffer whose spectrum was handed over last period
             const int head = (head0 + b) & (kSlots - 1);
-            float* const outb = out + (size_t)(ENGINE ? oslot : b) * step;
-            oslot = next_slot(oslot);
+            float* const outb = out + (size_t)b * step;
             cf z[16], y[8], park[8];
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];    // the forward wave writes the next one in interval 6
@@ -1318,13 +1233,7 @@ __device__ __forceinline__ void conv_split_resident(
             {
                 float* const o0 = outb + 4 * (size_t)d;
                 auto put = [&](float* dst, float a, float b2, float c2, float d2) {
-                    if (ENGINE && !GAB_EABL(2)) {                     // write-through: in memory before `completed` says so
-                        typedef float f4v __attribute__((ext_vector_type(4)));
-                        const f4v val = {a, b2, c2, d2};
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
-                    } else {
-                        *reinterpret_cast<float4*>(dst) = make_float4(a, b2, c2, d2);
-                    }
+                    *reinterpret_cast<float4*>(dst) = make_float4(a, b2, c2, d2);
                 };
                 if (pr == 0) {
 #pragma unroll
@@ -1341,10 +1250,528 @@ __device__ __forceinline__ void conv_split_resident(
                 }
             }
             GAB_BSTAMP(5);
-            close_period();
             __syncthreads();                                          // barrier 6 closes the period
             GAB_BSTAMP(6);
             if (!more) break;
+        }
+    }
+    // every wave is past the last closing barrier: the duo's carry ring goes back to memory
+    for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry_g[i] = carry[i];
+}
+
+
+__device__ __forceinline__ void conv_split_engine_resident(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0,
+    const ConvEngine& eng, cf* __restrict__ lds, unsigned* __restrict__ s_door) {
+    constexpr bool ENGINE = true;                                     // (GAB_BSTAMP's period choice; the GAB_ENGV experiments' conditions)
+    constexpr int n_buffers = 0;                                      // (GAB_ENGV bit 8 only: a batch launch's history rule)
+    (void)ENGINE; (void)n_buffers;
+    cf* const far_x = lds + 6 * kWaveImg;
+    cf* const far_y = far_x + kLdsHalf;
+    cf* const carry = far_y + kLdsHalf;                               // [pair of the duo][slot][512]
+    const int tid = threadIdx.x;
+    const int d = xcd_contiguous(blockIdx.x, gridDim.x);
+    const size_t step = (size_t)T * kB;
+    cf* const carry_g = sp.carry + (size_t)(2 * d) * kCarrySlots * kB;   // the duo's two rings are contiguous
+    for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry[i] = carry_g[i];
+    constexpr int kPoller = 2 * 64;                                   // lane 0 of the first inverse wave
+    // the doorbell as this workgroup may read it: workgroup 0 asks the host and passes the answer on, the others ask the relay
+    auto read_door = [&]() -> unsigned {
+        if (blockIdx.x == 0) {
+            const unsigned v = __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(eng.relay, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        }
+        return __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (tid == 0) s_door[2] = 0;
+    __syncthreads();
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    // WORKGROUP 0's first inverse wave is the aggregator: every inverse wave's count of finished buffers (8 per lane, sc1
+    // loads), the minimum into `completed` (pinned host word) — from the period loop and from the idle loop below
+    unsigned reported = 0;                                            // (meaningful in that wave only)
+    auto aggregate_request = [&](u4& a, u4& b) {
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc(eng.progress, 0, (int)(8u * gridDim.x), 0x00020000);
+        a = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane, 0, 16);          // sc1; beyond the end: zeros dropped below
+        b = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane + 16u, 0, 16);
+    };
+    auto aggregate_report = [&](const u4& a, const u4& b) {
+        const unsigned words = 2u * gridDim.x;                        // lanes beyond the array read zeros: mask them out
+        auto pick = [&](unsigned v, unsigned idx) { return idx < words ? v : 0xffffffffu; };
+        unsigned m = min(min(min(pick(a[0], 8u * lane), pick(a[1], 8u * lane + 1)), min(pick(a[2], 8u * lane + 2), pick(a[3], 8u * lane + 3))),
+                         min(min(pick(b[0], 8u * lane + 4), pick(b[1], 8u * lane + 5)), min(pick(b[2], 8u * lane + 6), pick(b[3], 8u * lane + 7))));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+        if (m != reported) {
+            reported = m;
+            if (lane == 0) __hip_atomic_store(eng.completed, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    // How many buffers may be touched, asked by EVERY wave — at the top of period nb of a burst (same answer in all of them:
+    // it is read from LDS, written before the previous period's closing barrier), and with idle = true between bursts.
+    // Batch launches: n_buffers.  The engine's doorbell word: bits 0-29 buffers published so far, bit 31 STOP (no more will
+    // come), bit 30 FLUSH (finish what is published without waiting for more).  A period runs buffer nb when buffer nb + 1
+    // is there too (its operands are requested one period ahead) — or, on STOP or FLUSH, when nb is the last one published:
+    // that period requests nothing, the burst ends behind it with a drain period, and the workgroup idles here until the
+    // doorbell moves (the next burst starts cold: a real-time caller with ONE buffer in flight rings FLUSH with every
+    // buffer).  Returns the count published (> nb), or -1: the stop rung with nothing pending — the launch ends.
+    auto gate = [&](int nb, bool idle) -> int {
+        {
+            if (idle && __builtin_amdgcn_readfirstlane(s_door[2]) != 0) return -1;   // the doorbell ran out of time in this burst: no further wait
+            bool look = !idle;                                        // an idle gate asks first: the word in LDS is the one the last burst ended on
+            for (;;) {
+                if (look) {
+                    // (the same word in every lane: said so, or every test on it becomes an exec-masked region — the far
+                    // role's request burst under a divergent branch took 2.4 instead of 1.4 us of its barrier interval)
+                    const unsigned D = __builtin_amdgcn_readfirstlane(s_door[nb & 1]);
+                    const int pub = (int)(D & 0x3fffffffu);
+                    const bool stop = (D >> 31) != 0, flush = ((D >> 30) & 1u) != 0;
+                    if (pub >= nb + 2 || ((stop || flush) && pub >= nb + 1)) return pub;
+                    if (stop) return -1;                              // nothing more will come
+                }
+                look = true;
+                __syncthreads();                                      // every wave has read the word
+                if (w == 2) {                                         // the first inverse wave polls (lane 0 asks; workgroup 0's also aggregates)
+                    unsigned v = 0;
+                    int tries = 0;
+                    for (;;) {
+                        u4 pa, pb;
+                        if (blockIdx.x == 0 && !GAB_EABL(1)) aggregate_request(pa, pb);
+                        unsigned mine = 0;
+                        if (lane == 0) mine = read_door();
+                        v = __builtin_amdgcn_readfirstlane(mine);
+                        if (blockIdx.x == 0 && !GAB_EABL(1)) aggregate_report(pa, pb);
+                        const int p2 = (int)(v & 0x3fffffffu);
+                        if (p2 >= nb + 2 || (v >> 31) || (((v >> 30) & 1u) && p2 >= nb + 1)) break;
+                        if (++tries > kEnginePollLimit) {             // the producer is gone: stop here, say so
+                            if (lane == 0) {
+                                __hip_atomic_store(eng.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                s_door[2] = 1;
+                            }
+                            v = 0x80000000u | (unsigned)(p2 < nb ? p2 : nb);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(20);
+                    }
+                    if (lane == 0) s_door[nb & 1] = v;
+                }
+                __syncthreads();
+            }
+        }
+    };
+    // buffer nb lives in slot nb % ring of the engine's rings (a batch launch: buffer nb itself); callers walk the slots
+    // with next_slot() instead of dividing
+    auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
+    auto next_slot = [&](int slot) -> int { return (ENGINE && slot + 1 == eng.ring) ? 0 : slot + 1; };
+    // The engine's input ring is rewritten while the launch runs (by copy engines): its loads are system-scope loads,
+    // answered by memory and never by a line an L1 or an L2 kept.  The rings are ORDINARY device memory (round 4, measured
+    // at 1024 channels: fine-grained rings read by non-temporal loads 6.85 us per buffer, ordinary rings read by
+    // system- or agent-scope loads 6.09-6.13, by plain loads — which may be stale — 6.2-6.3).
+    auto ld = [](const float* p) -> float {
+        if constexpr (ENGINE)
+            return GAB_EABL(4)     ? *p
+                   : GAB_EABL(256) ? __builtin_nontemporal_load(p)
+                                   : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc0 sc1
+        else return *p;
+    };
+
+    if (w >= 4) {
+        // ---- far waves: F of the pair whose turn it is (window = blocks k-7 .. k; the two newest straight from
+        // the input buffers, the next buffer's operands requested under the inverse transform); the share is
+        // parked in LDS
+        const int ft = tid - kThreads;
+        using FB = fft::BlockFFT<kNB, 16, false>;
+        using FBi = fft::BlockFFT<kNB, 16, true>;
+        typename FB::Twiddles twb;                                  // every pass's powers stay in registers
+        FB::load_twiddles(twb, tw, ft);
+        // (Measured, not kept: the next buffer's 36 requests spread over three barrier intervals instead of
+        // one burst after the spectral product — the burst's 0.6 us on the chain only moves: 5.75 vs 5.31 us.)
+        // Blocks that lie inside the launch come from the input buffers (block k-j = buffer nb-j), older ones
+        // from the history ring as the previous launch left it: the ring is neither read nor written in the
+        // steady state of a launch (the forward waves refresh it over the launch's last eight buffers).
+        // FIRST (a compile-time tag): the launch's first window, whose block k-1 is still the history ring's.  (As a
+        // run-time test on nb the engine's k-1 loads became conditional loads: a register merge behind them, i.e. a
+        // wait for the whole request burst in the middle of the far chain — 2.3 instead of 1.4 us for that interval.)
+        auto load_window = [&](auto first_tag, int nb, int slot, int slot_before, cf (&z)[16], float4 (&c)[16], int ft) {   // (ft: the caller's copy, see the bursts)
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int head = (head0 + nb) & (kSlots - 1);
+            const int q = 2 * d + (head & 1);
+            const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
+            const size_t ca = (size_t)(2 * q) * kB, cb_ = ca + kB;
+            const float* const cur = in_slot(slot);
+            z[14] = mk(ld(cur + ca + ft), ld(cur + cb_ + ft));
+            z[15] = mk(ld(cur + ca + ft + kThreads), ld(cur + cb_ + ft + kThreads));
+            if constexpr (ENGINE && !GAB_EABL(8)) {                   // k-1 from the input ring, the rest from the history ring
+                if constexpr (!FIRST) {
+                    const float* const prv = in_slot(slot_before);
+                    z[12] = mk(ld(prv + ca + ft), ld(prv + cb_ + ft));
+                    z[13] = mk(ld(prv + ca + ft + kThreads), ld(prv + cb_ + ft + kThreads));
+                } else {
+                    const int s = ((head + kSlots - 1) & (kSlots - 1)) * kB;
+                    z[12] = hp[s + ft];
+                    z[13] = hp[s + kThreads + ft];
+                }
+#pragma unroll
+                for (int r = 0; r < 12; ++r)
+                    z[r] = hp[((head + 1 + (r >> 1)) & (kSlots - 1)) * kB + (r & 1) * kThreads + ft];
+            } else if (nb >= kSlots - 1) {                            // the whole window lies inside the launch
+#pragma unroll
+                for (int bl = 0; bl < 7; ++bl) {
+                    int sb = slot - (7 - bl);                         // (engine experiments: the ring wraps)
+                    if (ENGINE && sb < 0) sb += eng.ring;
+                    const float* const src = in_slot(sb);
+                    z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
+                    z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
+                }
+            } else {
+#pragma unroll
+                for (int bl = 0; bl < 7; ++bl) {                      // block k-7+bl = buffer nb-7+bl (uniform branch)
+                    if (nb - 7 + bl >= 0) {
+                        const float* const src = in_slot(slot - (7 - bl));       // nb < 7: no wrap yet
+                        z[2 * bl] = mk(src[ca + ft], src[cb_ + ft]);
+                        z[2 * bl + 1] = mk(src[ca + ft + kThreads], src[cb_ + ft + kThreads]);
+                    } else {
+                        const int s = ((head + 1 + bl) & (kSlots - 1)) * kB;
+                        z[2 * bl] = hp[s + ft];
+                        z[2 * bl + 1] = hp[s + kThreads + ft];
+                    }
+                }
+            }
+            load_spectra<kNB, 16>(c, sp.pmF + (size_t)q * kBinsB, ft);
+        };
+        cf zb[16], zn[16];
+        float4 cb[16];
+        // one period of the far role: the transform of window nb, the next window's requests under its inverse
+        auto far_period = [&](int nb, int slot, int avail) {
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(4)) {                                        // diagnostic builds: far role idle
+                for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
+                return;
+            }
+#endif
+            const int head = (head0 + nb) & (kSlots - 1);
+            cf* const cp = carry + (head & 1) * kCarrySlots * kB;
+            GAB_BSTAMP(6);
+#ifdef GAB_ABLATE
+            FB::run(zb, far_x, far_y, twb, ft, true, [&](int p) { GAB_BSTAMP(p); });
+#else
+            FB::run(zb, far_x, far_y, twb, ft);                       // barriers 1, 2
+#endif
+            partner_exchange<kNB, 16, true>(zb, zn, far_x, ft);       // barrier 3
+            GAB_BSTAMP(2);
+            spectral_product<kNB, 16>(zb, zn, cb, ft);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef GAB_ABLATE
+            if (!GAB_SDBG(512)) { keep_alive(zb[0]); keep_alive(zb[15]); GAB_BSTAMP(7); }      // slot 7: the product is done
+#endif
+            if (nb + 1 < avail) load_window(std::false_type{}, nb + 1, next_slot(slot), slot, zn, cb, ft);   // flies under the inverse transform
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(512)) GAB_BSTAMP(7);                                                   // or: the request burst has been issued
+#endif
+#ifdef GAB_ABLATE
+            FBi::template run<typename FB::Twiddles, 4>(zb, far_y, far_x, twb, ft, true, [&](int p) { GAB_BSTAMP(3 + p); });
+#else
+            FBi::template run<typename FB::Twiddles, 4>(zb, far_y, far_x, twb, ft);   // barriers 4, 5; only [12..15]
+#endif
+            cf* const c1 = cp + ((head + 1) & (kCarrySlots - 1)) * kB;              // block k+1
+            cf* const c2 = cp + ((head + 2) & (kCarrySlots - 1)) * kB;              // block k+2
+            c1[ft] = zb[12];
+            c1[ft + kThreads] = zb[13];
+            c2[ft] = zb[14];
+            c2[ft + kThreads] = zb[15];
+            __syncthreads();                                          // barrier 6 closes the period
+            GAB_BSTAMP(5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zb[r] = zn[r];
+        };
+        int nb = 0, slot = 0;                                         // the next buffer and its ring slot
+        for (;;) {                                                    // bursts
+            int avail = gate(nb, true);
+            if (nb >= avail) break;
+            {
+                // (an opaque copy of the thread index: inside the loop over bursts the window's burst-invariant
+                // 64-bit addresses would otherwise be hoisted out of that loop and spilled)
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_window(std::true_type{}, nb, slot, 0, zb, cb, fo);   // a burst starts cold: block k-1 is the history ring's
+            }
+            for (;;) {
+                far_period(nb, slot, avail);
+                ++nb;
+                slot = next_slot(slot);
+                if (nb >= avail) break;                               // nothing was requested for buffer nb: the burst ends here
+                avail = gate(nb, false);
+                if (nb >= avail) break;                               // (the doorbell ran out of time)
+            }
+            for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // the burst's drain period: the inverse waves' alone
+        }
+    } else if (w < 2) {
+        // ---- forward waves: wave w holds pair w of the duo
+        const int q = 2 * d + w;
+        cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const img = lds + w * kWaveImg;                           // the transform's exchanges, then its spectrum
+        cf* const hand = lds + (2 + w) * kWaveImg;                    // output spectrum for the inverse wave
+        using WF = fft::WaveFFT1024<false>;
+        WF::Lean t;
+        WF::load_twiddles(t, tw, lane);
+        const float4* const pa = pmA + (size_t)q * kBinsA;
+        const float4* const pa2 = sp.pmA2 + (size_t)q * kBinsA;
+        const size_t xoff = (size_t)(2 * q) * kB;                     // channel a of a buffer; channel b is kB further
+        cf z[16], prev[8], nxt[8];
+        float4 c[16];
+        // one period of the forward wave
+        auto fwd_period = [&](int nb, int slot, int avail) {
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(1)) {                                        // diagnostic builds: near role idle
+                for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();
+                return;
+            }
+#endif
+            // One piece of work per barrier interval (the far role's transform has six):
+            //   A2 share | window + pass 0 | pass 1 | pass 2 | spectrum + A product | hand-over + requests
+            const int head = (head0 + nb) & (kSlots - 1);
+            cf share[16];                                     // taps [512,1024): last period's spectrum x pmA2
+            {
+                cf vp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) share[r] = img[rb + 68 * r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+                spectral_product<kNA, 16>(share, vp, c, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // an opaque copy of the lane index: sixteen loop-invariant 64-bit addresses would otherwise be
+                // hoisted out of the loop, spilled, and reloaded one by one between the loads they feed
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                load_spectra<kNA, 16>(c, pa, lo);             // for this buffer's A product (interval 5)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_BSTAMP(0);
+            __syncthreads();                                  // barrier 1
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
+            if ((ENGINE && !GAB_EABL(8)) || nb + kSlots >= n_buffers) {   // the ring only has to hold the launch's LAST eight blocks
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
+            if (nb + 1 < avail) {                             // the next buffer's block: needed a period from now
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = in_slot(next_slot(slot)) + xoff + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(ld(xa + 64 * j), ld(xa + kB + 64 * j));
+            }
+#ifdef GAB_ABLATE
+            WF::run(z, img, t, lane, [&](int i) { GAB_BSTAMP(1 + i); __syncthreads(); });
+#else
+            WF::run(z, img, t, lane, ArriveAtBarrier());      // barriers 2, 3 from inside
+#endif
+            GAB_BSTAMP(3);
+            __syncthreads();                                  // barrier 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];     // the spectrum stays here for the next period
+            __builtin_amdgcn_wave_barrier();
+            {
+                cf zp[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+                spectral_product<kNA, 16>(z, zp, c, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                load_spectra<kNA, 16>(c, pa2, lo);            // for the next period's A2 share
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_BSTAMP(4);
+            __syncthreads();                                  // barrier 5
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = fft::cadd(z[r], share[r]);   // A product + A2 share
+            GAB_BSTAMP(5);
+            __syncthreads();                                  // barrier 6 closes the period
+            GAB_BSTAMP(6);
+        };
+        int nb = 0, slot = 0;                                         // the next buffer and its ring slot
+        bool primed = false;                                          // the image holds the spectrum of blocks [k-2 | k-1]
+        for (;;) {                                                    // bursts
+            int avail = gate(nb, true);
+            if (nb >= avail) break;
+            if (!primed) {
+                // the launch's first burst: the spectrum of the ring's blocks [k-2 | k-1] into the image.  (Later bursts
+                // find it there — the last period left the spectrum of [k-1 | k], which is the next buffer's [k-2 | k-1] —
+                // with block k-1 in `prev` and the A2 spectra in `c`: only the new block is loaded.)
+                const int s1 = ((head0 + kSlots - 1) & (kSlots - 1)) * kB, s2 = ((head0 + kSlots - 2) & (kSlots - 1)) * kB;
+                int lo = lane;                                    // (inside the loop: see the far role)
+                asm volatile("" : "+v"(lo));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lo + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) prev[j] = hp[s1 + lo + 64 * j];
+                // (the burst's first block is asked for below, as in every burst: registers)
+                load_spectra<kNA, 16>(c, pa2, lo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[8 + j] = prev[j];
+                WF::run(z, img, t, lane, WF::NoHook());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+                __builtin_amdgcn_wave_barrier();
+                primed = true;
+            }
+            {                                                     // the burst's first block
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = in_slot(slot) + xoff + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(ld(xa + 64 * j), ld(xa + kB + 64 * j));
+            }
+            for (;;) {
+                fwd_period(nb, slot, avail);
+                ++nb;
+                slot = next_slot(slot);
+                if (nb >= avail) break;                               // nothing was requested for buffer nb: the burst ends here
+                avail = gate(nb, false);
+                if (nb >= avail) break;
+            }
+            for (int i = 0; i < kBatchBarriers; ++i) __syncthreads();    // the burst's drain period
+        }
+    } else {
+        // ---- inverse waves: wave 2 + p turns the output spectrum of pair p into samples, one period later
+        const int pr = w - 2;
+        const cf* const hand = lds + (2 + pr) * kWaveImg;
+        cf* const img = lds + (4 + pr) * kWaveImg;                    // the transform's exchanges, then the output swap
+        const cf* const other = lds + (4 + (1 - pr)) * kWaveImg;
+        const cf* const cring = carry + pr * kCarrySlots * kB;
+        using WFi = fft::WaveFFT1024<true>;
+        WFi::Lean t;
+        WFi::load_twiddles(t, tw, lane);
+        int oslot = 0;                                                // of the next buffer to leave
+        int nb = 0, avail = 0, base = 0;                              // the period, buffers that may be touched, the burst's first buffer
+        bool boundary = true;                                         // between bursts (the launch's start is a boundary)
+        for (;;) {                                                    // periods base .. end of every burst; in a burst's last one only this role works (the drain)
+            if (boundary) {
+                avail = gate(nb, true);
+                if (nb >= avail) break;
+                base = nb;                                            // nothing to turn in a burst's first period
+                boundary = false;
+            } else if (nb < avail) {
+                avail = gate(nb, false);                              // (nb == avail: the drain period — the other roles ask nothing either)
+            }
+            const bool more = nb < avail;                         // the other roles work on buffer nb in this period
+            unsigned door_next = s_door[nb & 1];                  // (no per-period poll: the word as last seen)
+            u4 prog_a = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, prog_b = prog_a;
+            if constexpr (ENGINE) {
+                if (nb >= base + 2 && !GAB_EABL(1)) {
+                    // this wave's rows of buffer nb - 2 were stored a period ago: drained by now, so the wait is free,
+                    // and the count of finished buffers can go out (write-through, nobody waits for it)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)(nb - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == kPoller && eng.poll_every_period)      // asked now, needed at the period's end
+                    door_next = blockIdx.x == 0 ? __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) aggregate_request(prog_a, prog_b);
+            }
+            auto close_period = [&]() {                           // before the closing barrier
+                if constexpr (ENGINE) {
+                    if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) aggregate_report(prog_a, prog_b);
+                    if (tid == kPoller) {
+                        s_door[(nb + 1) & 1] = door_next;
+                        if (blockIdx.x == 0 && eng.poll_every_period)
+                            __hip_atomic_store(eng.relay, door_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            };
+            bool idle_period = nb == base;                        // a burst's first period: nothing to turn yet
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(1)) idle_period = true;                  // diagnostic builds: near role idle
+#endif
+            if (idle_period) {
+                for (int i = 0; i < kBatchBarriers - 1; ++i) __syncthreads();
+                close_period();
+                __syncthreads();
+            } else {
+                // One piece per barrier interval: hand-over read | pass 0 | pass 1 | pass 2 + far share | swap | stores
+                const int b = nb - 1;                             // the buffer whose spectrum was handed over last period
+                const int head = (head0 + b) & (kSlots - 1);
+                float* const outb = out + (size_t)(ENGINE ? oslot : b) * step;
+                oslot = next_slot(oslot);
+                cf z[16], y[8], park[8];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];    // the forward wave writes the next one in interval 6
+#pragma unroll
+                for (int j = 0; j < 8; ++j) park[j] = cring[(head & (kCarrySlots - 1)) * kB + lane + 64 * j];
+                GAB_BSTAMP(0);
+                __syncthreads();                                  // barrier 1
+#ifdef GAB_ABLATE
+                WFi::run(z, img, t, lane, [&](int i) { GAB_BSTAMP(1 + i); __syncthreads(); });
+#else
+                WFi::run(z, img, t, lane, ArriveAtBarrier());     // barriers 2, 3 from inside
+#endif
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+                GAB_BSTAMP(3);
+                __syncthreads();                                  // barrier 4
+                // the two pairs of a duo are four neighbouring channels: the waves swap halves through LDS
+                // so that each stores float4 pieces (pair 0 keeps samples lane + 64 j, j < 4, pair 1 j >= 4)
+                if (pr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[4 + j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
+                }
+                GAB_BSTAMP(4);
+                __syncthreads();                                  // barrier 5: the swapped halves are in LDS
+                {
+                    float* const o0 = outb + 4 * (size_t)d;
+                    auto put = [&](float* dst, float a, float b2, float c2, float d2) {
+                        if (ENGINE && !GAB_EABL(2)) {             // write-through: in memory before `completed` says so
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            const f4v val = {a, b2, c2, d2};
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+                        } else {
+                            *reinterpret_cast<float4*>(dst) = make_float4(a, b2, c2, d2);
+                        }
+                    };
+                    if (pr == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const cf theirs = other[lane + 64 * j];
+                            put(o0 + (size_t)T * (lane + 64 * j), y[j].x, y[j].y, theirs.x, theirs.y);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const cf theirs = other[lane + 64 * j];
+                            put(o0 + (size_t)T * (lane + 64 * (4 + j)), theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                        }
+                    }
+                }
+                GAB_BSTAMP(5);
+                close_period();
+                __syncthreads();                                  // barrier 6 closes the period
+                GAB_BSTAMP(6);
+            }
+            if (!more) {
+                // the burst is through: this wave's last rows must be in memory before its count says so (the one wait for
+                // stores on this path: a workgroup that goes idle has nothing to hide it behind)
+                if (!GAB_EABL(1)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                boundary = true;
+                continue;
+            }
+            ++nb;
         }
     }
     // every wave is past the last closing barrier: the duo's carry ring goes back to memory
@@ -1355,15 +1782,15 @@ __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
     __shared__ cf lds[kBatchLds];
-    conv_split_resident<false>(in, out, hist, pmA, sp, tw, T, head0, n_buffers, ConvEngine{}, lds, nullptr);
+    conv_split_batch_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds);
 }
 
 __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_engine_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, ConvEngine eng) {
     __shared__ cf lds[kBatchLds];
-    __shared__ unsigned door[2];
-    conv_split_resident<true>(in, out, hist, pmA, sp, tw, T, head0, 0, eng, lds, door);
+    __shared__ unsigned door[4];          // [0], [1] the doorbell as last seen, by period parity; [2] the engine has given up
+    conv_split_engine_resident(in, out, hist, pmA, sp, tw, T, head0, eng, lds, door);
 }
 
 // IR bank -> (P, M) spectra of a near (512 taps from offA) and a far (taps from offB) partition.
@@ -1658,6 +2085,18 @@ static int gab_split_debug_mask() {
 #define GAB_SPLIT_DEBUG_ARG
 #endif
 
+// The block the plan consumed last, as the kernels keep it (the newest slot of the history ring), back in the input's
+// layout [tracks][512] — for checks of the round trip's upload hand-off: it must equal the h_in of the last call.
+__global__ void conv_newest_block_kernel(const float* __restrict__ hist, float* __restrict__ out, int T, int slot) {
+    const int q = blockIdx.x;
+    const gab::fft::cf* const hp = reinterpret_cast<const gab::fft::cf*>(hist) + ((size_t)q * gab::kSlots + slot) * gab::kB;
+    for (int i = threadIdx.x; i < gab::kB; i += blockDim.x) {
+        const gab::fft::cf v = hp[i];
+        out[(size_t)(2 * q) * gab::kB + i] = v.x;
+        if (2 * q + 1 < T) out[(size_t)(2 * q + 1) * gab::kB + i] = v.y;
+    }
+}
+
 struct gab_conv_plan {
     int tracks = 0, bufsize = 0, ir_len = 0;
     int pairs = 0;
@@ -1689,6 +2128,7 @@ struct gab_conv_plan {
     unsigned* rt_words = nullptr;       // pinned host: [0] done, [16] landed, [32] error (a 64-byte line each)
     hipStream_t rt_copy_stream = nullptr;
     hipEvent_t rt_copy_ev = nullptr;
+    hipEvent_t rt_done_ev = nullptr;      // the launch's own completion (what gab_conv_round_trip returns on)
     unsigned rt_epoch = 0;
     int rt_groups = 0, rt_pairs_per_group = 0;
     const void* rt_checked_out = nullptr;
@@ -1801,6 +2241,11 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
 
 int gab_conv_destroy(gab_conv_plan* p) {
     if (!p) return GAB_OK;
+    if (p->eng_running) {                                            // never leave a resident launch behind: ring the stop rung FIRST
+        if (p->eng_words) __atomic_store_n(&p->eng_words[0], p->eng_published | 0x80000000u, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(p->eng_stream);                   // (a null handle is the default stream)
+        p->eng_running = false;
+    }
     (void)hipDeviceSynchronize();
     if (p->pmA) (void)hipFree(p->pmA);
     if (p->pmB) (void)hipFree(p->pmB);
@@ -1817,15 +2262,12 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->rt_park) (void)hipFree(p->rt_park);
     if (p->rt_counters) (void)hipFree(p->rt_counters);
     if (p->rt_words) (void)hipHostFree(p->rt_words);
-    if (p->eng_running) {                                            // never leave a resident launch behind
-        if (p->eng_words) __atomic_store_n(&p->eng_words[0], p->eng_published | 0x80000000u, __ATOMIC_RELEASE);
-        (void)hipDeviceSynchronize();
-    }
     if (p->eng_in) (void)hipFree(p->eng_in);
     if (p->eng_out) (void)hipFree(p->eng_out);
     if (p->eng_done) (void)hipFree(p->eng_done);
     if (p->eng_words) (void)hipHostFree(p->eng_words);
     if (p->rt_copy_ev) (void)hipEventDestroy(p->rt_copy_ev);
+    if (p->rt_done_ev) (void)hipEventDestroy(p->rt_done_ev);
     if (p->rt_copy_stream) (void)hipStreamDestroy(p->rt_copy_stream);
     delete p;
     return GAB_OK;
@@ -2008,6 +2450,7 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
     GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
     GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_copy_ev, hipEventDisableTiming));
+    GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_done_ev, hipEventDisableTiming));
     GAB_HIP_CHECK(hipDeviceSynchronize());
     p->rt_epoch = 0;
 }
@@ -2045,71 +2488,119 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         }
         p->order_after_reset(s);
         const size_t bytes = sizeof(float) * (size_t)p->tracks * p->bufsize;
-        const unsigned epoch = ++p->rt_epoch;
+        // the device counters run on from launch to launch and are compared with epoch x members: the plan's epoch moves
+        // only when a launch has really been made
+        const unsigned epoch = p->rt_epoch + 1;
         volatile unsigned* const done = p->rt_words;
-        volatile unsigned* const landed = p->rt_words + 16;
+        unsigned* const landed = p->rt_words + 16;
         volatile unsigned* const error = p->rt_words + 32;
         bool upload = true;
+        // How the launch's end is observed: kRtCompletion (measured, profiles/r05_roundtrip_completion.txt).
+        //   0 hipStreamSynchronize   1 an event recorded behind the launch, queried   2 the launch's own stop event
+        //   (hipExtLaunchKernelGGL), queried   3 hipStreamQuery   9 (diagnostic builds only) round 4's rule: the hint word
+        int completion = gab::kRtCompletion;
 #ifdef GAB_ABLATE
         if (getenv("GAB_RT_SKIP_UPLOAD")) upload = false;   // diagnostic builds: the input never lands — every wait must run out
+        if (getenv("GAB_RT_COMPLETION")) completion = atoi(getenv("GAB_RT_COMPLETION"));   // diagnostic builds: to price the rules
 #endif
         // The kernel takes a word the moment it is no longer the sentinel and puts the sentinel back: that is only right
         // if the upload writes every word exactly ONCE — one engine copy from pinned (or device) memory does.  What the
         // runtime does with PAGEABLE memory (staging pieces, heads and tails on their own) is its own business: such an
         // input is uploaded completely first and announced as landed before the launch.  (profiles/r04_incident_*)
+        // h_in is read by the copy from the moment of this call: it must be complete on the host (or, for device memory,
+        // on the device) by then — the upload runs on the plan's own stream and is NOT ordered behind work queued on `stream`.
         bool streamed = true;
         bool may_stream_pageable = false;
 #ifdef GAB_ABLATE
         if (getenv("GAB_RT_STREAM_PAGEABLE")) may_stream_pageable = true;      // diagnostic builds: the form the incident was met with
 #endif
+        // put the stage back to all-sentinel and the upload stream to rest (after anything that may have left words behind)
+        auto rearm_stage = [&]() {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(p->rt_copy_stream);
+            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, (size_t)p->tracks * p->bufsize);
+            (void)hipDeviceSynchronize();
+        };
         if (upload && !may_stream_pageable && !mapped(h_in)) {
             GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
             GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
-            *landed = epoch;
+            __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);
             streamed = false;
         } else if (upload) {
             GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
         }
         gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
                               epoch, p->rt_pairs_per_group, p->rt_groups};
-        gab::conv_round_trip_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(rt, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
+        if (completion == 2)
+            hipExtLaunchKernelGGL(gab::conv_round_trip_kernel, dim3(p->pairs), dim3(gab::kThreads), 0, s, nullptr, p->rt_done_ev, 0,
+                                  rt, p->hist, (const float4*)p->pmA, (const float4*)p->pmB, (const gab::fft::cf*)p->tw, p->tracks, p->head);
+        else
+            gab::conv_round_trip_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(rt, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head);
         int rc = gab::launch_status("conv_round_trip_kernel");
+        if (!rc && completion == 1) GAB_HIP_CHECK(hipEventRecord(p->rt_done_ev, s));
+        if (rc) {                                       // nothing ran: the epoch, the history and the counters stay as they were
+            if (upload) rearm_stage();                  // (the upload did: its words must not pass for the next call's)
+            return rc;
+        }
+        p->rt_epoch = epoch;
         if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
         p->head = (p->head + 1) & (gab::kSlots - 1);
         p->fresh = false;
-        if (rc) return rc;
-        // the pinned word says the output is complete; the upload's event releases workgroups whose rows really
-        // hold the sentinel
-        bool told = !upload || !streamed;               // (diagnostic: nothing was uploaded, nothing is announced)
         // After a wait that ran out, words may land behind the sentinel the kernel put back and the kernel has taken
         // sentinels for samples: the launch bounds its own waits, so let it end (also before the caller may free the
         // buffers), put the stage back to all-sentinel, and say that the carried history now holds garbage.
         auto after_a_failed_wait = [&](const char* what) {
-            (void)hipStreamSynchronize(s);
-            (void)hipStreamSynchronize(p->rt_copy_stream);
-            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, (size_t)p->tracks * p->bufsize);
-            (void)hipDeviceSynchronize();
+            rearm_stage();
             *error = 0;
             gab::set_last_error(std::string("gab_conv_round_trip: ") + what +
                                 "; the output of this call is invalid and so is the plan's carried history (gab_conv_reset before the stream goes on)");
             return GAB_ERR_RUNTIME;
         };
+        // 1. The upload: its completion event releases workgroups whose rows really hold the sentinel (`landed`, a release
+        //    store the kernel acquires).  The copy is through well before the kernel (its last group is still to be
+        //    transformed and drained), so this costs the call nothing.
+        // 2. The hint word, so that the stream is asked once, when the launch is about to end (its waits are bounded: it
+        //    ends by itself, with or without the hint).
+        // 3. The launch's end: the stated point from which h_out is the host's and the staging buffer the next upload's.
+        bool told = !upload || !streamed;               // (diagnostic: nothing was uploaded, nothing is announced)
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
-        while (*done != epoch) {
-            if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) { *landed = epoch; told = true; }
-            if ((++spins & 1023u) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0)
-                return after_a_failed_wait("the launch did not report completion within 4 s");
+        bool ended = false;
+        while (!told || *done != epoch) {
+            if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) { __atomic_store_n(landed, epoch, __ATOMIC_RELEASE); told = true; }
+            if ((++spins & 1023u) == 0) {
+                if (told && hipStreamQuery(s) == hipSuccess) { ended = true; break; }      // over without the hint: a wait ran out
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0)
+                    return after_a_failed_wait("the launch did not end within 4 s");
+            }
         }
-        if (!told) *landed = epoch;
+        (void)hipGetLastError();                        // (hipStreamQuery's hipErrorNotReady)
+        if (ended || completion == 0) {
+            GAB_HIP_CHECK(hipStreamSynchronize(s));
+        } else if (completion != 9) {
+            for (spins = 0;;) {
+                const hipError_t q = completion == 3 ? hipStreamQuery(s) : hipEventQuery(p->rt_done_ev);
+                if (q == hipSuccess) break;
+                (void)hipGetLastError();
+                if (q != hipErrorNotReady) GAB_HIP_CHECK(q);
+                if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0)
+                    return after_a_failed_wait("the launch did not end within 4 s");
+            }
+        }
         if (*error != 0) return after_a_failed_wait("a workgroup waited about a second for its input and gave up");
-        // The completion word rests on a store to pinned memory counting as ordered once its wave's vmcnt has drained, for
-        // the rows of OTHER compute units too.  From 8 MiB of output on (8192 channels: a 0.65 ms call) the call also
-        // waits for the launch itself to end — a few microseconds, under 1 % there; the 2 MiB real-time case keeps the
-        // word alone.  (profiles/r04_incident_roundtrip_8192_mismatch.txt: cause not established.)
-        if (bytes >= (size_t(8) << 20)) GAB_HIP_CHECK(hipStreamSynchronize(s));
+        if (*done != epoch) return after_a_failed_wait("the launch ended without draining every channel group");
         return GAB_OK;
+    });
+}
+
+int gab_conv_newest_block(gab_conv_plan* p, float* d_out, gab_stream_t stream) {
+    return gab::guarded([&]() -> int {
+        if (!p || !d_out) return gab::bad_arg("gab_conv_newest_block: null argument");
+        if (!p->fused || p->fresh) return gab::bad_arg("gab_conv_newest_block: a 512-sample plan that has taken at least one buffer");
+        if (p->eng_running) return gab::bad_arg("gab_conv_newest_block: the plan's engine is running");
+        conv_newest_block_kernel<<<dim3(p->pairs), dim3(256), 0, gab::as_stream(stream)>>>(
+            p->hist, d_out, p->tracks, (p->head + gab::kSlots - 1) & (gab::kSlots - 1));
+        return gab::launch_status("conv_newest_block_kernel");
     });
 }
 
@@ -2188,12 +2679,39 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
     });
 }
 
-int gab_conv_engine_publish(gab_conv_plan* p, int n_more) {
-    if (!p || !p->eng_running) return gab::bad_arg("gab_conv_engine_publish: no running engine");
-    if (n_more < 0) return gab::bad_arg("gab_conv_engine_publish: negative count");
+int gab_conv_engine_submit(gab_conv_plan* p, int n_more, int flush) {
+    if (!p || !p->eng_running) return gab::bad_arg("gab_conv_engine_submit: no running engine");
+    if (n_more < 0) return gab::bad_arg("gab_conv_engine_submit: negative count");
+    if (p->eng_published + (unsigned)n_more >= 0x40000000u) return gab::bad_arg("gab_conv_engine_submit: more than 2^30 buffers in one launch (stop and start again)");
     p->eng_published += (unsigned)n_more;
-    __atomic_store_n(&p->eng_words[0], p->eng_published, __ATOMIC_RELEASE);       // the doorbell: buffers published so far
+    // the doorbell: buffers published so far; bit 30 = finish them without waiting for more (one store: count and rung together)
+    __atomic_store_n(&p->eng_words[0], p->eng_published | (flush ? 0x40000000u : 0u), __ATOMIC_RELEASE);
     return GAB_OK;
+}
+
+int gab_conv_engine_publish(gab_conv_plan* p, int n_more) { return gab_conv_engine_submit(p, n_more, 0); }
+
+int gab_conv_engine_wait(gab_conv_plan* p, int count, double timeout_seconds) {
+    return gab::guarded([&]() -> int {
+        if (!p || !p->eng_words) return gab::bad_arg("gab_conv_engine_wait: no engine");
+        if (count < 0 || (unsigned)count > p->eng_published) return gab::bad_arg("gab_conv_engine_wait: count exceeds what has been published");
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        int done = 0;
+        for (;;) {
+            gab_conv_engine_completed(p, &done);
+            if (done >= count) return GAB_OK;
+            if (p->eng_words[32]) {
+                gab::set_last_error("gab_conv_engine_wait: the engine gave up waiting for the doorbell");
+                return GAB_ERR_RUNTIME;
+            }
+            if ((++spins & 0xfffu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds) {
+                gab::set_last_error("gab_conv_engine_wait: " + std::to_string(done) + " of " + std::to_string(count) +
+                                    " buffers reported within the time limit (without the flush rung a buffer is reported once five later ones are published)");
+                return GAB_ERR_RUNTIME;
+            }
+        }
+    });
 }
 
 int gab_conv_engine_completed(gab_conv_plan* p, int* completed) {

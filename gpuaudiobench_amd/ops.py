@@ -227,6 +227,13 @@ class ConvPlan:
         check(lib.gab_conv_round_trip(self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr()), st))
         return h_out
 
+    def newest_block(self):
+        """The block the plan consumed last ([tracks*512], the input's layout), from its history ring
+        (gab_conv_newest_block): what a round trip's upload hand-off is checked against."""
+        out = torch.empty(self.tracks * self.bufsize, dtype=torch.float32, device="cuda")
+        check(lib.gab_conv_newest_block(self._h, _dev(out), _stream()))
+        return out
+
     def prepare_round_trip(self, h_in, h_out, stream=None):
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         return (self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr()), st)
@@ -254,6 +261,15 @@ class ConvPlan:
 
     def engine_publish(self, n_more=1):
         check(lib.gab_conv_engine_publish(self._h, n_more))
+
+    def engine_submit(self, n_more=1, flush=True):
+        """Publish n_more buffers; flush=True also rings the flush rung: finish what is published without
+        waiting for more (the real-time form, one buffer in flight)."""
+        check(lib.gab_conv_engine_submit(self._h, n_more, 1 if flush else 0))
+
+    def engine_wait(self, count, timeout=10.0):
+        """Spins until `count` buffers are reported complete (gab_conv_engine_wait)."""
+        check(lib.gab_conv_engine_wait(self._h, count, float(timeout)))
 
     def engine_completed(self):
         v = C.c_int(0)

@@ -219,11 +219,21 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * over the link itself (as GAB_CONV_STREAMING_HOST_IO; h_in must then be pinned as well) and the call waits
  * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  h_in: pinned for the overlap; pageable
  * memory is accepted and uploaded completely before the launch (the kernel consumes an upload as it lands only when every
- * word is written exactly once, which one engine copy from pinned memory does).  Blocking; one call at a time
- * per plan.  GAB_ERR_RUNTIME if the input never arrived: the output of that call is then invalid AND so is the
+ * word is written exactly once, which one engine copy from pinned memory does).  h_in is read from the moment of the
+ * call on the plan's own upload stream: it must be complete by then (the upload is NOT ordered behind work queued on
+ * `stream`).  Blocking; one call at a time per plan.  The call returns when the LAUNCH HAS ENDED on `stream`
+ * (hipStreamSynchronize): from then on h_out is the host's and the staging buffer the next call's — the completion
+ * rule of cuda/bench_base.cu:30-42,177-179 (copy back after a device synchronisation), not a word the kernel writes.
+ * GAB_ERR_RUNTIME if the input never arrived: the output of that call is then invalid AND so is the
  * plan's carried history (the kernel took placeholders for samples) — gab_conv_reset before the stream goes on;
- * the staging buffer has been re-armed, the next call works.                                               */
+ * the staging buffer has been re-armed, the next call works.  A launch that could not be made leaves the plan as it
+ * was (history, epoch, staging buffer).                                                                      */
 int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
+/* The block the plan consumed LAST, as its kernels keep it (the newest slot of the history ring of a 512-sample
+ * plan), written to d_out in the input's layout [tracks][512].  An inspection call (additive): after
+ * gab_conv_round_trip it must equal that call's h_in word for word — the check of the upload hand-off that tests
+ * and tools/roundtrip_stress.py make.                                                                         */
+int gab_conv_newest_block(gab_conv_plan* plan, float* d_out, gab_stream_t stream);
 /* ---- a resident engine fed through a doorbell (additive; split-cut plans) -----------------------------------------
  * For a caller whose buffers ARRIVE one at a time but who can keep a couple in flight: ONE launch (the batch launch's
  * kernel) stays on the device and convolves buffer k as soon as the host — or anything that can write the slot — has
@@ -235,10 +245,16 @@ int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, ga
  *             cannot: at 1024 channels the engine holds every compute unit until it stops);
  *   start     the same rings, and launches on `stream`, which the launch occupies until stop;
  *   publish   after buffer k has been written to slot k % ring_buffers: the doorbell count goes up by n_more;
- *   completed buffers whose output is complete in its slot.  The engine asks for a buffer one period before it uses it,
- *             delivers one period after, counts a period later and passes the doorbell on inside the device, so buffer
- *             k is reported once k + 5 is published (or the stop rung): keep at least six in flight, and a ring
- *             of at least seven slots.  A producer reuses slot k % ring only when completed > k - ring;
+ *   submit    publish with a rung: flush != 0 says "finish what is published, do not wait for more" — the real-time form,
+ *             ONE buffer in flight: a period then runs buffer k although k + 1 is not there (it requests nothing for it),
+ *             a drain period delivers it and its count is reported at once; the engine idles until the doorbell moves and
+ *             takes the next buffer cold (cuda/bench_conv1d_accel.cu:258-304: one buffer per iteration).  With two or more
+ *             buffers pending the engine pipelines as before, whatever the rung says;
+ *   completed buffers whose output is complete in its slot.  Pipelined (no flush): the engine asks for a buffer one period
+ *             before it uses it, delivers one period after, counts a period later and passes the doorbell on inside the
+ *             device, so buffer k is reported once k + 5 is published (or the flush / stop rung): keep at least six in
+ *             flight, and a ring of at least seven slots.  A producer reuses slot k % ring only when completed > k - ring;
+ *   wait      spins until completed >= count (GAB_ERR_RUNTIME after timeout_seconds, or if the engine gave up);
  *   feed      a host loop for resident rings: rings the doorbell n_buffers times, one buffer each, never more than
  *             `ahead` (6 <= ahead < ring_buffers) in front of `completed`;
  *   stop      rings the stop bit, waits for the launch to end (every published buffer is finished), carries the
@@ -250,6 +266,8 @@ int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, ga
 int gab_conv_engine_rings(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring);
 int gab_conv_engine_start(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring, gab_stream_t stream);
 int gab_conv_engine_publish(gab_conv_plan* plan, int n_more);
+int gab_conv_engine_submit(gab_conv_plan* plan, int n_more, int flush);
+int gab_conv_engine_wait(gab_conv_plan* plan, int count, double timeout_seconds);
 int gab_conv_engine_completed(gab_conv_plan* plan, int* completed);
 int gab_conv_engine_feed(gab_conv_plan* plan, int n_buffers, int ahead);
 int gab_conv_engine_stop(gab_conv_plan* plan);

@@ -453,33 +453,44 @@ def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, 
     h_out = torch.empty(T * B).pin_memory()
     hist = np.zeros(T * L, np.float32)
     worst = peak = 0.0
+    prev = {"out": None, "in": None}
+
+    def compared_round_trip(x, src, label):
+        """One gab_conv_round_trip against the device-buffer launch of the same input, set up so that a single
+        mismatch says which hand-off failed (tests/rt_diag.py): NaN-filled output, the consumed block read back."""
+        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+        h_out.fill_(float("nan"))
+        yb = b.round_trip(src, h_out).numpy().copy()
+        consumed = host(b.newest_block())
+        report = rt_diag.classify(ya, yb, T, B, prev_out=prev["out"], h_in=x, consumed=consumed, prev_in=prev["in"], label=label)
+        assert not report, report
+        prev["out"], prev["in"] = yb, x
+        return yb
+
+    import rt_diag
     for i in range(n):
         x = orc.noise(T * B, seed=90 + i)
-        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
-        h_in.copy_(torch.from_numpy(x))
-        h_out.fill_(float("nan"))
         if i % 5 == 3:                                   # a device-buffer launch in the middle of the stream
+            ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
             yb = host(b.process(dev(x), mode=gab.CONV_STREAMING))
+            assert not where_bits_differ(ya, yb, T), "buffer %d: %s" % (i, where_bits_differ(ya, yb, T))
+            prev["out"], prev["in"] = yb, x
         else:
-            yb = b.round_trip(h_in, h_out).numpy().copy()     # complete when the call returns: no synchronize here
-        assert not where_bits_differ(ya, yb, T), "buffer %d: %s" % (i, where_bits_differ(ya, yb, T))
+            h_in.copy_(torch.from_numpy(x))
+            yb = compared_round_trip(x, h_in, "buffer %d" % i)     # complete when the call returns: no synchronize here
         if T <= 64:
             ref = orc.conv_accel_stream(x, ir_h, hist, L, B, T, f64=True)
             worst, peak = max(worst, float(np.abs(yb - ref).max())), max(peak, float(np.abs(ref).max()))
     if T <= 64:
         assert worst / peak <= 1e-5
-    # a pageable input: every group comes by the engine copy (a pinned one lets the kernel read the first group itself)
+    # a pageable input: uploaded completely before the launch
     x = orc.noise(T * B, seed=8)
-    ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
-    yb = b.round_trip(torch.from_numpy(x.copy()), h_out).numpy().copy()
-    assert not where_bits_differ(ya, yb, T), "pageable input: %s" % where_bits_differ(ya, yb, T)
+    compared_round_trip(x, torch.from_numpy(x.copy()), "pageable input")
     # the staging buffer is re-armed after every buffer: the same input twice in a row is two buffers, not one
     x = orc.noise(T * B, seed=7)
     h_in.copy_(torch.from_numpy(x))
     for k in range(2):
-        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
-        yb = b.round_trip(h_in, h_out).numpy().copy()
-        assert not where_bits_differ(ya, yb, T), "same input, call %d: %s" % (k, where_bits_differ(ya, yb, T))
+        compared_round_trip(x, h_in, "same input, call %d" % k)
     a.close()
     b.close()
 
@@ -581,6 +592,75 @@ def test_conv_accel_engine_fed_through_the_doorbell_same_bits(gab, orc):
         assert np.array_equal(bits(got[k]), bits(want[2 + k])), "buffer %d" % k
     with pytest.raises(gab.GabError):
         b.engine_publish(1)                          # no running engine
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("T", [64, 1024])
+def test_conv_accel_engine_one_buffer_in_flight(gab, orc, T):
+    """The real-time form of the engine (cuda/bench_conv1d_accel.cu:258-304 takes ONE buffer per iteration): the host
+    writes buffer k into its slot, rings the doorbell WITH the flush rung, waits for `completed` = k + 1 and only then
+    produces buffer k + 1 — nothing else is ever pending.  Every output bit for bit what one gab_conv_process launch per
+    buffer gives: 50 buffers back to back, 12 paced at 512/48000 s, then a pipelined stretch (six published at once) and
+    single buffers again on the SAME launch — bursts of any length walk one history — and ordinary launches after the stop."""
+    import time
+    import torch
+    B, L, R = 512, 4096, 8
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    N = 50 + 12 + 6 + 5
+    xs = [orc.noise(T * B, seed=400 + i) for i in range(N + 1)]
+    want = [host(a.process(dev(x), mode=gab.CONV_STREAMING)) for x in xs]
+    side = torch.cuda.Stream()
+    in_ring, out_ring = b.engine_start(R, stream=side)
+    cur = torch.cuda.current_stream()
+    h_in, h_out = torch.empty(T * B).pin_memory(), torch.empty(T * B).pin_memory()
+
+    def put(k):                                      # copy ENGINES move the slots: at 1024 channels the launch holds every compute unit
+        h_in.copy_(torch.from_numpy(xs[k]))
+        in_ring[k % R].copy_(h_in, non_blocking=True)
+        cur.synchronize()
+
+    def take(k):
+        h_out.copy_(out_ring[k % R], non_blocking=True)
+        cur.synchronize()
+        assert np.array_equal(bits(h_out.numpy()), bits(want[k])), "buffer %d" % k
+
+    k = 0
+    for _ in range(50):                              # back to back, one in flight
+        put(k)
+        b.engine_submit(1, flush=True)
+        b.engine_wait(k + 1, timeout=8.0)
+        assert b.engine_completed() == k + 1
+        take(k)
+        k += 1
+    daw = gab.harness.DawSim(buffer_seconds=float(B) / 48000, mode="spin")
+    for _ in range(12):                              # one buffer per 10.667 ms slot: the engine idles in between
+        daw.wait()
+        put(k)
+        t0 = time.perf_counter()
+        b.engine_submit(1, flush=True)
+        b.engine_wait(k + 1, timeout=8.0)
+        assert time.perf_counter() - t0 < 0.010667, "missed the slot"
+        take(k)
+        k += 1
+    for j in range(6):                               # six pending at once: the engine pipelines them, the rung ends the burst
+        put(k + j)
+    b.engine_submit(6, flush=True)
+    b.engine_wait(k + 6, timeout=8.0)
+    for j in range(6):
+        take(k + j)
+    k += 6
+    for _ in range(5):
+        put(k)
+        b.engine_submit(1, flush=True)
+        b.engine_wait(k + 1, timeout=8.0)
+        take(k)
+        k += 1
+    b.engine_stop()
+    assert np.array_equal(bits(host(b.process(dev(xs[k]), mode=gab.CONV_STREAMING))), bits(want[k]))
     a.close()
     b.close()
 

@@ -1,10 +1,16 @@
 """gab_conv_round_trip against device-buffer launches of the same cut at a large channel count, many buffers, pinned and
-pageable inputs mixed; on a mismatch prints WHERE (channels, samples, channel groups) instead of only that.
+pageable inputs mixed.  Every compared call is set up so that ONE mismatch classifies itself (tests/rt_diag.py): h_out is
+refilled with NaN, the block the kernel consumed is read back and compared with h_in, the previous call's input and
+output are kept.
     python tools/roundtrip_stress.py [channels] [buffers]"""
+import os
 import sys
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import gpuaudiobench_amd as gab
+import rt_diag
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 B, L = 512, 4096
@@ -13,23 +19,27 @@ a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="cl
 a.set_ir(ir); b.set_ir(ir)
 h_in, h_out = torch.empty(T * B).pin_memory(), torch.empty(T * B).pin_memory()
 bad = 0
+prev_out = prev_in = None
 for i in range(N):
     x = gab.harness.noise(T * B, seed=1000 + i)
     ya = a.process(torch.from_numpy(x).cuda()).cpu().numpy()
     h_out.fill_(float("nan"))
-    if i % 3 == 1:
-        yb = b.round_trip(torch.from_numpy(x.copy()), h_out).numpy().copy()       # pageable input
+    pageable = i % 3 == 1
+    if pageable:
+        yb = b.round_trip(torch.from_numpy(x.copy()), h_out).numpy().copy()
     else:
         h_in.copy_(torch.from_numpy(x))
         yb = b.round_trip(h_in, h_out).numpy().copy()
-    d = ya.view(np.uint32) != yb.view(np.uint32)
-    if d.any():
+    consumed = b.newest_block().cpu().numpy()
+    report = rt_diag.classify(ya, yb, T, B, prev_out=prev_out, h_in=x, consumed=consumed, prev_in=prev_in,
+                              label="buffer %d (%s input)" % (i, "pageable" if pageable else "pinned"))
+    if report:
         bad += 1
-        idx = np.flatnonzero(d)
-        smp, ch = idx // T, idx % T
-        print("buffer %d (%s input): %d words differ; samples %d..%d (%d distinct), channels %d..%d (%d distinct), groups %s; NaN in round trip: %d; first: got %r want %r"
-              % (i, "pageable" if i % 3 == 1 else "pinned", idx.size, smp.min(), smp.max(), np.unique(smp).size, ch.min(), ch.max(), np.unique(ch).size,
-                 sorted(set((ch // 512).tolist()))[:8], int(np.isnan(yb).sum()), yb[idx[0]], ya[idx[0]]), flush=True)
+        print(report, flush=True)
         # both plans go on from the device-buffer result's state: re-synchronise b's history with a's
         b.reset(); a.reset()
-print("%d buffers, %d with a mismatch" % (N, bad))
+        prev_out = prev_in = None
+    else:
+        prev_out, prev_in = yb, x
+print("%d buffers at %d channels, %d with a mismatch" % (N, T, bad))
+sys.exit(1 if bad else 0)
