@@ -111,15 +111,22 @@ def dry_run(args, rank, world):
     import torch
     import torch.distributed as dist
     from gpuaudiobench_amd import sharding
-    T, L = int(os.environ.get("GAB_BENCH_DRYRUN_TRACKS", "8")), 64
+    # (GAB_BENCH_DRYRUN_TRACKS / _TAPS: 1024 / 4096 walk BASELINE configs[4]'s shape arithmetic with 8 ranks — 8192
+    # channels, a 128 MiB bank, 1024-channel slices at global indices: tests/test_bench_launcher.py)
+    T, L = int(os.environ.get("GAB_BENCH_DRYRUN_TRACKS", "8")), int(os.environ.get("GAB_BENCH_DRYRUN_TAPS", "64"))
+    gran = sharding.shard_granule("Conv1D_accel")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     t0 = time.perf_counter()
-    ir = sharding.broadcast_ir_bank(L, T * world, rank, world, torch.device("cpu"), dist if world > 1 else None)
+    ir = sharding.broadcast_ir_bank(L, T * world, rank, world, torch.device("cpu"), dist if world > 1 else None,
+                                    granule=gran, distribution=args.ir_distribution)
     bcast_ms = (time.perf_counter() - t0) * 1e3
-    lo, hi = sharding.shard_range(rank, world, T * world)
-    ok = bool(np.array_equal(ir.numpy().ravel(), __import__("gpuaudiobench_amd").harness.conv_accel_ir(L, hi - lo, lo, T * world)))
+    lo, hi = sharding.shard_range(rank, world, T * world, gran)
+    ok = bool(hi - lo == T and np.array_equal(ir.numpy().ravel(), __import__("gpuaudiobench_amd").harness.conv_accel_ir(L, hi - lo, lo, T * world)))
+    # the rank's input rows and its output columns at the job's global indices (no device: the rows stand in for outputs)
+    x = sharding.shard_noise(T * world, 4, rank, world, seed=42, granule=gran)
+    ok = ok and x.shape == (T, 4)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -137,7 +144,8 @@ def dry_run(args, rank, world):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "DRY RUN (GAB_BENCH_DRYRUN=1): rendezvous, bank broadcast and collectives "
                                   "on CPU over gloo; no device work, no measurement",
-                          "config": {"workload": "dry run", "ir_broadcast_ms": bcast_ms,
+                          "config": {"workload": "dry run", "ir_broadcast_ms": bcast_ms, "ir_distribution": args.ir_distribution,
+                                     "channels_total": T * world, "taps": L, "channels_per_rank": T,
                                      "ir_slices_match_global_bank": ok}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -157,6 +165,8 @@ def main():
                     help="also time 8 / 16 / 32 buffers per launch (off by default: those launches carry the headline "
                          "kernel's name and would mix into a profiler's per-kernel average of the 128-buffer launches)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--ir-distribution", choices=("broadcast", "slices"), default="broadcast",
+                    help="N > 1: every rank receives the whole impulse-response bank (north_star's RCCL broadcast) or only its rows")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -203,7 +213,9 @@ def main():
     from gpuaudiobench_amd import sharding
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ir_dev = sharding.broadcast_ir_bank(L, T_total, rank, world, dev, dist if grouped else None)
+    gran = sharding.shard_granule("Conv1D_accel")
+    ir_dev = sharding.broadcast_ir_bank(L, T_total, rank, world, dev, dist if grouped else None, granule=gran,
+                                        distribution=args.ir_distribution)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if grouped else None
 
@@ -214,7 +226,7 @@ def main():
         raise SystemExit("bench.py: the headline shape must run the split cut")
 
     # ---- synthetic input: the reference's noise generator, this rank's channels --
-    host_in = [sharding.shard_noise(T_total, B, rank, world, seed=42 + i) for i in range(NB)]
+    host_in = [sharding.shard_noise(T_total, B, rank, world, seed=42 + i, granule=gran) for i in range(NB)]
     xb = torch.cat([torch.from_numpy(x).reshape(-1) for x in host_in]).to(dev)        # [NB][T*B], resident
     yb = torch.empty_like(xb)                                             # [NB][B*T]
     stream = torch.cuda.current_stream()
@@ -299,7 +311,7 @@ def main():
                            "streamed through HBM" % (NB * T * B * 4 >> 20, NB * T * B * 4 >> 20),
             "clock_warm_steps": args.clock_warm_steps,
             "realtime_factor": (world * n_buffers / elapsed) * B / FS,
-            "ir_broadcast_ms": bcast_ms, "collective_backend": backend,
+            "ir_broadcast_ms": bcast_ms, "ir_distribution": args.ir_distribution if grouped else None, "collective_backend": backend,
             "state_bytes": {"spectra": spectra_bytes, "history": history_bytes},
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GAB_")},
         },
@@ -484,6 +496,40 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
         "frac": alg / eng_us / 1e3 / HBM_PEAK_GBS, "buffers": passes * NB, "ahead": ahead, "ring_slots": NB,
         "untimed_first_launch_buffers": eng_warm_passes * NB,
         "bit_identical_to_batch_launches": bool(torch.equal(out_ring.reshape(-1).view(torch.int32), yref.view(torch.int32)))}
+    # The same engine with ONE buffer in flight (the reference's iteration takes one buffer and returns it,
+    # cuda/bench_conv1d_accel.cu:258-304): ring the doorbell with the flush rung, wait for `completed` to count THAT buffer,
+    # only then the next.  Host clock around each { submit, wait } (gab_conv_engine_feed_one_in_flight); the same buffers,
+    # so the output ring must again be what the batch launches left.  Then paced: one buffer per 512/48000 s slot.
+    eplan.reset()
+    out_ring.zero_()
+    torch.cuda.synchronize()
+    lat = np.zeros(passes * NB, np.float32)
+    eplan.engine_start(NB, stream=side)
+    eplan.engine_feed_one_in_flight(passes * NB, lat)
+    eplan.engine_stop()
+    side.synchronize()
+    lone_same = bool(torch.equal(out_ring.reshape(-1).view(torch.int32), yref.view(torch.int32)))
+    eplan.engine_start(NB, stream=side)
+    daw1 = gab.harness.DawSim(buffer_seconds=float(B) / FS, mode="spin")
+    paced1 = np.zeros(1, np.float32)
+    paced_lat = []
+    for i in range(65):
+        daw1.wait()
+        eplan.engine_feed_one_in_flight(1, paced1)
+        if i >= 5:
+            paced_lat.append(float(paced1[0]))
+    eplan.engine_stop()
+    side.synchronize()
+    daw1.close()
+    lat = lat[100:]
+    res["one_buffer_per_doorbell"]["in_flight_1"] = {
+        "what": "ONE buffer in flight: doorbell with the flush rung -> completed counts that buffer -> next (input and output in the "
+                "engine's device rings; the link is config.round_trip's business); us from publish to completed, host clock",
+        "p50_us": float(np.percentile(lat, 50)), "p95_us": float(np.percentile(lat, 95)), "max_us": float(lat.max()),
+        "buffers": int(len(lat)),
+        "paced_10p667ms": {"p50_us": float(np.percentile(paced_lat, 50)), "max_us": float(np.max(paced_lat)), "buffers": len(paced_lat)},
+    }
+    res["one_buffer_per_doorbell"]["bit_identical_in_flight_1"] = lone_same
     eplan.close()
     plan.reset()
     NB, xb = NB_step, xb_step

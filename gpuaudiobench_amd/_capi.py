@@ -110,6 +110,7 @@ PROTOTYPES = {
     "gab_conv_engine_wait": (_I, [_P, _I, C.c_double]),
     "gab_conv_engine_completed": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_engine_feed": (_I, [_P, _I, _I]),
+    "gab_conv_engine_feed_one_in_flight": (_I, [_P, _I, _P]),
     "gab_conv_engine_stop": (_I, [_P]),
     "gab_conv_state_bytes": (_I, [_P, C.POINTER(_Z), C.POINTER(_Z)]),
     "gab_fdtd_default_params": (_I, [_I, _I, _I, C.POINTER(FdtdParams)]),

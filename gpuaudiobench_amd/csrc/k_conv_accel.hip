@@ -600,9 +600,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 //   down  outputs are parked sample-major in device memory by write-through stores; the workgroup whose arrival
 //         completes a channel group (the copy lands groups in order) drains the group's slab to the pinned output in
 //         whole rows of the group's width, so the link carries 256-512-byte pieces while later groups are still landing;
-//   done  the call returns when the LAUNCH HAS ENDED (hipStreamSynchronize on the caller's stream).  The drain that
+//   done  the call returns when the LAUNCH HAS ENDED (its own stop event: hipExtLaunchKernelGGL + hipEventQuery).  The drain that
 //         completes the last group also writes the epoch to a pinned word: a hint that tells the spinning host when to go
-//         and wait for the stream, nothing more.
+//         and ask the event, nothing more.
 // What each hand-off rests on (round 5; profiles/r05_roundtrip_protocol.md has the reasoning and the record it answers):
 //   upload -> kernel   a naturally aligned 32-bit word is single-copy atomic (HSA), so a word read as "not the sentinel" is
 //         the input word — given that the copy writes every word ONCE with its final value (one linear engine copy from
@@ -612,9 +612,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 //         that really IS the sentinel is accepted only behind an acquire of `landed`, which the host releases after it has
 //         seen the copy's completion event (HSA: a completed copy's writes are visible at system scope).
 //   re-arm -> next upload   the sentinel stores belong to a launch that has ended before the call returns, and the next
-//         call's copy is submitted after that: ordered by the stream synchronisation, not by a counter.
+//         call's copy is submitted after that: ordered by the launch's completion, not by a counter.
 //   rows -> host   the rows are the launch's stores to pinned memory; the host reads them after the launch's completion
-//         signal (HIP: everything a kernel wrote is visible to the host once its stream has been synchronised).
+//         signal (HIP: everything a kernel wrote is visible to the host once the launch's event has completed).
 // Same operations in the same order as conv_overlap_save_kernel<true, true>: bit-identical to device-buffer launches.
 constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
@@ -2561,7 +2561,7 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         //    transformed and drained), so this costs the call nothing.
         // 2. The hint word, so that the stream is asked once, when the launch is about to end (its waits are bounded: it
         //    ends by itself, with or without the hint).
-        // 3. The launch's end: the stated point from which h_out is the host's and the staging buffer the next upload's.
+        // 3. The launch's end (its stop event): the stated point from which h_out is the host's and the staging buffer the next upload's.
         bool told = !upload || !streamed;               // (diagnostic: nothing was uploaded, nothing is announced)
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
@@ -2746,6 +2746,21 @@ int gab_conv_engine_feed(gab_conv_plan* p, int n_buffers, int ahead) {
         if (p->eng_words[32]) {
             gab::set_last_error("gab_conv_engine_feed: the engine gave up waiting for the doorbell");
             return GAB_ERR_RUNTIME;
+        }
+        return GAB_OK;
+    });
+}
+
+int gab_conv_engine_feed_one_in_flight(gab_conv_plan* p, int n_buffers, float* latency_us) {
+    return gab::guarded([&]() -> int {
+        if (!p || !p->eng_running) return gab::bad_arg("gab_conv_engine_feed_one_in_flight: no running engine");
+        if (n_buffers < 0) return gab::bad_arg("gab_conv_engine_feed_one_in_flight: negative count");
+        // the real-time loop for resident rings: ring the doorbell with the flush rung, wait for that very buffer, go on
+        for (int i = 0; i < n_buffers; ++i) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (int rc = gab_conv_engine_submit(p, 1, 1)) return rc;
+            if (int rc = gab_conv_engine_wait(p, (int)p->eng_published, 5.0)) return rc;
+            if (latency_us) latency_us[i] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
         }
         return GAB_OK;
     });

@@ -8,6 +8,7 @@
 // through LDS in coalesced rows, and the waveguide is re-cut into independent
 // delay-line cells.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdint>
 
@@ -687,14 +688,15 @@ __global__ __launch_bounds__(256) void dwg_gather_kernel(const int2* __restrict_
 __global__ __launch_bounds__(256) void dwg_mix_kernel(const int2* __restrict__ hits,
                                                      const float* __restrict__ ws,
                                                      float* __restrict__ out, int n_wg, int B,
-                                                     int out_tracks, const int* __restrict__ mix_count,
-                                                     const int2* __restrict__ mix_list) {
+                                                     int out_tracks, const int* mix_count,
+                                                     const int2* __restrict__ mix_list, bool zero_counts) {
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= B) return;
     float acc = 0.0f;
     const int n = n_wg < out_tracks ? n_wg : out_tracks;
     const int c = mix_count ? mix_count[s] : kMixCap + 1;  // wave-uniform; no lists: the scan
+    if (zero_counts && lane == 0 && c != 0) const_cast<int*>(mix_count)[s] = 0;    // (c is in hand: the load is through) the pool's slot goes back to zero
     if (c <= kMixCap) {
         int key = 0x7fffffff;
         float val = 0.0f;
@@ -744,6 +746,81 @@ __global__ __launch_bounds__(256) void dwg_mix_kernel(const int2* __restrict__ h
         }
     }
     if (lane == 0) out[s] = acc;
+}
+
+// ---- banks of two thousand mixed waveguides and more: the cells kernel appends to the hit lists itself (round 5) ---------
+// Round 4 took three launches at 8 192 lines: cells 17.2 us + gather 6.2 + mix 4.3.  The gather — one thread per waveguide
+// appending (g, tap value) to the list of every sample it reaches — was a second pass over values the cells kernel had just
+// produced, and a kernel boundary.  Here the thread that owns the output tap's cell appends as it goes.  (Its atomics
+// requested BEFORE the cell loads, so that their round trip runs beside the loads': 27 more registers per thread, five
+// waves per SIMD instead of seven, 29.4 us instead of 17 — not kept.)  The per-sample counters must be ZERO before the first append, which no
+// workgroup of the same launch can guarantee for the others: they live in a zero-initialised array of the code object
+// (one slot per call in flight, kDwgSlots of them, picked round robin by the host) and the mix kernel puts every counter
+// back to zero behind itself.  (All three steps in ONE launch — the launch's last workgroups waiting for every other
+// one's appends, then mixing — was built and measured: 27.7 us, the three launches' time; profiles/r05_dwg_one_launch.txt.)
+// Same operations per cell in the same order as dwg_cells_multi_kernel, same ordered sum: bit-identical.
+constexpr int kDwgSlots = 16;
+constexpr int kDwgMaxB = 2048;
+__device__ int g_dwg_count[kDwgSlots][kDwgMaxB];      // hits per sample; zero between calls
+
+template <int U>
+__global__ __launch_bounds__(256) void dwg_cells_append_kernel(const WG* __restrict__ wgs,
+                                                              float* __restrict__ fwd, float* __restrict__ bwd,
+                                                              const float* __restrict__ input,
+                                                              float* __restrict__ ws, int2* __restrict__ hits,
+                                                              int2* __restrict__ mix_list, int n_wg, int n_mix, int B,
+                                                              int max_len, int slot) {
+    __shared__ float xin[kDwgMaxB];
+    int* const count = g_dwg_count[slot];
+    const int g0 = blockIdx.y * U;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) xin[i] = input[i];
+    __syncthreads();
+    const int s0 = blockIdx.x * blockDim.x + threadIdx.x;
+    WG wg[U];
+    float f[U], b[U];
+    float* F[U];
+    float* Bk[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int g = g0 + u;
+        live[u] = false;
+        if (g >= n_wg) continue;
+        wg[u] = wgs[g];
+        if (blockIdx.x == 0 && threadIdx.x == 0) dwg_publish_hits(wg[u], g, hits);
+        live[u] = s0 < wg[u].length && s0 < B;
+        int p = wrap_once(wg[u].writePos, wg[u].length) + s0;      // both below L (live threads): conditional subtractions
+        if (p >= wg[u].length) p -= wg[u].length;
+        int bp = p + wg[u].length / 2;
+        if (bp >= wg[u].length) bp -= wg[u].length;
+        F[u] = fwd + (size_t)g * max_len + p;
+        Bk[u] = bwd + (size_t)g * max_len + bp;
+        wg[u].pad = __int_as_float(p);                     // the cell, kept where the record has room
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (live[u]) { f[u] = *F[u]; b[u] = *Bk[u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        const int g = g0 + u;
+        const int p = __float_as_int(wg[u].pad);
+        const bool inject = (p == wg[u].inTap), tap = (p == wg[u].outTap);
+        float mix;
+        for (int s = s0; s < B; s += wg[u].length) {
+            float x = __fmul_rn(xin[s], wg[u].gain);
+            dwg_step(f[u], b[u], x, inject, wg[u], mix);
+            if (tap) {
+                ws[(size_t)g * B + s] = mix;                        // (the crowded-sample scan's copy)
+                if (g < n_mix) {
+                    const int idx = atomicAdd(&count[s], 1);
+                    if (idx < kMixCap) mix_list[(size_t)s * kMixCap + idx] = make_int2(g, __float_as_int(mix));
+                }
+            }
+        }
+        *F[u] = f[u];
+        *Bk[u] = b[u];
+    }
 }
 
 }  // namespace
@@ -856,7 +933,21 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
         } else {
             int cells = max_len < bufsize ? max_len : bufsize;   // a buffer visits min(L, B) cells of a line
             constexpr int U = 8;
-            if (n_waveguides >= 1024) {                          // large banks: U lines per workgroup (see the kernel)
+            if (sparse && bufsize <= gab::kDwgMaxB) {            // large banks: the cells kernel appends to the hit lists itself
+                static std::atomic<unsigned> next_slot{0};
+                const int slot = (int)(next_slot.fetch_add(1) % (unsigned)gab::kDwgSlots);
+                int* pool = nullptr;
+                GAB_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&pool), HIP_SYMBOL(gab::g_dwg_count)));
+                dim3 grid((cells + 255) / 256, (n_waveguides + U - 1) / U);
+                gab::dwg_cells_append_kernel<U><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, n_waveguides,
+                                                                     n_mix, bufsize, max_len, slot);
+                int rc = gab::launch_status("dwg_cells_append_kernel");
+                if (rc) return rc;
+                gab::dwg_mix_kernel<<<(bufsize + 3) / 4, 256, 0, s>>>(hits, ws, d_out, n_waveguides, bufsize, out_tracks,
+                                                                      pool + (size_t)slot * gab::kDwgMaxB, mix_list, true);
+                return gab::launch_status("dwg_mix_kernel");
+            }
+            if (n_waveguides >= 1024) {                          // U lines per workgroup (see the kernel)
                 dim3 grid((cells + 255) / 256, (n_waveguides + U - 1) / U);
                 gab::dwg_cells_multi_kernel<U><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, n_waveguides,
                                                                     bufsize, max_len, mix_count);
@@ -874,7 +965,7 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
             if (rc) return rc;
         }
         gab::dwg_mix_kernel<<<(bufsize + 3) / 4, 256, 0, s>>>(hits, ws, d_out, n_waveguides, bufsize,
-                                                              out_tracks, mix_count, mix_list);
+                                                              out_tracks, mix_count, mix_list, false);
         return gab::launch_status("dwg_mix_kernel");
     });
 }

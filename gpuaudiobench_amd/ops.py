@@ -279,6 +279,15 @@ class ConvPlan:
     def engine_feed(self, n_buffers, ahead=4):
         check(lib.gab_conv_engine_feed(self._h, n_buffers, ahead))
 
+    def engine_feed_one_in_flight(self, n_buffers, latencies=None):
+        """n_buffers times { doorbell with the flush rung; wait for that buffer } on resident rings; latencies: a
+        float32 numpy array of n_buffers (host clock, us) or None."""
+        ptr = None
+        if latencies is not None:
+            assert latencies.dtype.name == "float32" and latencies.size >= n_buffers and latencies.flags["C_CONTIGUOUS"]
+            ptr = latencies.ctypes.data_as(C.c_void_p)
+        check(lib.gab_conv_engine_feed_one_in_flight(self._h, n_buffers, ptr))
+
     def engine_stop(self):
         check(lib.gab_conv_engine_stop(self._h))
 

@@ -38,12 +38,42 @@ def shard_granule(name):
     return GRANULE.get(name, 1)
 
 
-def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=0):
+def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=0, granule=1, distribution="broadcast"):
     """Returns this rank's slice (tracks x ir_len, contiguous, on `device`) of the
-    global conv1d_accel bank.  Rank `src` generates the whole bank."""
-    lo, hi = shard_range(rank, world, total_tracks)
+    global conv1d_accel bank.  Rank `src` generates the whole bank.
+
+    granule: the SAME cut as the shard's data (shard_granule(name): 4 for Conv1D_accel) — ranges cut with different
+    granules disagree whenever total_tracks is no multiple of world * granule, and slices would land on the wrong rows.
+    distribution: "broadcast" — every rank receives the whole bank and keeps its rows (north_star's RCCL broadcast;
+    total_tracks x ir_len x 4 bytes per rank: 128 MiB at C5) — or "slices": `src` sends every rank ITS rows only
+    (dist.scatter: send/recv pairs, one xGMI link per peer; 16 MiB per rank at C5, and no rank but `src` ever holds
+    the whole bank).  Same slices either way (test_sharding_gloo.py)."""
+    lo, hi = shard_range(rank, world, total_tracks, granule)
     if dist is None:                # no process group: one rank makes its own bank
         return torch.from_numpy(harness.conv_accel_ir(ir_len, hi - lo, lo, total_tracks)).to(device)
+    if distribution == "slices":
+        mine = torch.empty((hi - lo) * ir_len, dtype=torch.float32, device=device)
+        parts = None
+        if rank == src:
+            bank = torch.from_numpy(harness.conv_accel_ir(ir_len, total_tracks)).to(device).view(total_tracks, ir_len)
+            parts = []
+            for r in range(world):
+                a, b = shard_range(r, world, total_tracks, granule)
+                parts.append(bank[a:b].reshape(-1).contiguous())
+        if all(shard_range(r, world, total_tracks, granule)[1] - shard_range(r, world, total_tracks, granule)[0] == hi - lo
+               for r in range(world)):
+            dist.scatter(mine, parts, src=src)
+        else:                        # uneven shards: scatter wants equal sizes — point-to-point instead
+            if rank == src:
+                reqs = [dist.isend(parts[r], dst=r) for r in range(world) if r != src]
+                mine.copy_(parts[src])
+                for q in reqs:
+                    q.wait()
+            else:
+                dist.recv(mine, src=src)
+        return mine.view(hi - lo, ir_len)
+    if distribution != "broadcast":
+        raise ValueError("distribution must be 'broadcast' or 'slices'")
     bank = torch.empty(total_tracks * ir_len, dtype=torch.float32, device=device)
     if rank == src:
         bank.copy_(torch.from_numpy(harness.conv_accel_ir(ir_len, total_tracks)))
@@ -51,18 +81,18 @@ def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=
     return bank.view(total_tracks, ir_len)[lo:hi].contiguous()
 
 
-def shard_noise(total_tracks, bufsize, rank, world, seed=42):
+def shard_noise(total_tracks, bufsize, rank, world, seed=42, granule=1):
     """The reference's noise is one flat track-major stream over ALL tracks
-    (cuda/bench_utils.cu:238-245); a rank takes the rows of its tracks."""
-    lo, hi = shard_range(rank, world, total_tracks)
+    (cuda/bench_utils.cu:238-245); a rank takes the rows of its tracks (granule: as broadcast_ir_bank)."""
+    lo, hi = shard_range(rank, world, total_tracks, granule)
     flat = harness.noise(total_tracks * bufsize, seed)
     return np.ascontiguousarray(flat.reshape(total_tracks, bufsize)[lo:hi])
 
 
-def scatter_columns(global_out, shard_out, rank, world, total_tracks, bufsize):
+def scatter_columns(global_out, shard_out, rank, world, total_tracks, bufsize, granule=1):
     """Places a rank's sample-major result [s][local t] into the global
-    sample-major buffer [s][T_total] (out[T*s + t] with the GLOBAL stride)."""
-    lo, hi = shard_range(rank, world, total_tracks)
+    sample-major buffer [s][T_total] (out[T*s + t] with the GLOBAL stride; granule: as broadcast_ir_bank)."""
+    lo, hi = shard_range(rank, world, total_tracks, granule)
     global_out.reshape(bufsize, total_tracks)[:, lo:hi] = shard_out.reshape(bufsize, hi - lo)
     return global_out
 

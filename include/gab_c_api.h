@@ -222,7 +222,7 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * word is written exactly once, which one engine copy from pinned memory does).  h_in is read from the moment of the
  * call on the plan's own upload stream: it must be complete by then (the upload is NOT ordered behind work queued on
  * `stream`).  Blocking; one call at a time per plan.  The call returns when the LAUNCH HAS ENDED on `stream`
- * (hipStreamSynchronize): from then on h_out is the host's and the staging buffer the next call's — the completion
+ * (the launch's own stop event has completed): from then on h_out is the host's and the staging buffer the next call's — the completion
  * rule of cuda/bench_base.cu:30-42,177-179 (copy back after a device synchronisation), not a word the kernel writes.
  * GAB_ERR_RUNTIME if the input never arrived: the output of that call is then invalid AND so is the
  * plan's carried history (the kernel took placeholders for samples) — gab_conv_reset before the stream goes on;
@@ -255,6 +255,8 @@ int gab_conv_newest_block(gab_conv_plan* plan, float* d_out, gab_stream_t stream
  *             device, so buffer k is reported once k + 5 is published (or the flush / stop rung): keep at least six in
  *             flight, and a ring of at least seven slots.  A producer reuses slot k % ring only when completed > k - ring;
  *   wait      spins until completed >= count (GAB_ERR_RUNTIME after timeout_seconds, or if the engine gave up);
+ *   feed_one_in_flight   the real-time loop for resident rings: n_buffers times { submit(1, flush); wait for that buffer },
+ *             the host-clock time of each into latency_us[i] (may be null);
  *   feed      a host loop for resident rings: rings the doorbell n_buffers times, one buffer each, never more than
  *             `ahead` (6 <= ahead < ring_buffers) in front of `completed`;
  *   stop      rings the stop bit, waits for the launch to end (every published buffer is finished), carries the
@@ -270,6 +272,7 @@ int gab_conv_engine_submit(gab_conv_plan* plan, int n_more, int flush);
 int gab_conv_engine_wait(gab_conv_plan* plan, int count, double timeout_seconds);
 int gab_conv_engine_completed(gab_conv_plan* plan, int* completed);
 int gab_conv_engine_feed(gab_conv_plan* plan, int n_buffers, int ahead);
+int gab_conv_engine_feed_one_in_flight(gab_conv_plan* plan, int n_buffers, float* latency_us);
 int gab_conv_engine_stop(gab_conv_plan* plan);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,

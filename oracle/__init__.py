@@ -306,6 +306,20 @@ def fdtd(P, grids, x, out, tracks, bufsize, first_sample, n_samples, fused=True)
     return out
 
 
+def fdtd_trackwise(P, grids, x, out, tracks, bufsize, first_sample, n_samples, fused=True, order=None):
+    """orc_fdtd with the source cell as one order of the reference's atomicAdd leaves it: the tracks' samples
+    accumulate into the cell one by one (order: a permutation of range(tracks); None = ascending)."""
+    p, vx, vy, vz = grids
+    o = None
+    if order is not None:
+        o = np.ascontiguousarray(order, np.int32)
+        assert sorted(o.tolist()) == list(range(tracks))
+    lib().orc_fdtd_trackwise(C.byref(P), _p(p), _p(vx), _p(vy), _p(vz), _p(_f32(x)), _p(out),
+                             C.c_int(tracks), C.c_int(bufsize), C.c_int(first_sample),
+                             C.c_int(n_samples), C.c_int(1 if fused else 0), _p(o) if o is not None else None)
+    return out
+
+
 def fdtd_tracks(P, grids, x, out, tracks, bufsize, first_sample, n_samples, src_xyz, rcv_xyz, fused=True):
     """Track-dependent source / receiver cells (tracks x 3 int32 each, (x, y, z))."""
     p, vx, vy, vz = grids

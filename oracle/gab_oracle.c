@@ -576,6 +576,28 @@ void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
     }
 }
 
+/* The source cell as ONE ORDER OF THE REFERENCE'S atomicAdd leaves it (cuda/bench_fdtd3d.cu:101-120: every track adds
+ * 0.1f*in[t,s] to p[src], order unspecified): the scaled samples accumulate INTO THE CELL one by one, tracks in `order`
+ * (NULL: ascending) — p = (((p + a_0) + a_1) + ...), where orc_fdtd adds the tracks' own sum once, p + ((a_0 + a_1) + ...),
+ * a grouping no atomic order produces (it can differ in the cell's last bit).  The bit-exact tests pin orc_fdtd's order
+ * (the kernels' definition); this form bounds what that choice is worth against the reference.          */
+void orc_fdtd_trackwise(const orc_fdtd_params* P, float* p, float* vx, float* vy,
+                        float* vz, const float* in, float* out, int tracks, int bufsize,
+                        int first_sample, int n_samples, int fused, const int* order) {
+    const size_t sxy = (size_t)P->nx * P->ny;
+    const size_t src = (size_t)P->src_z * sxy + (size_t)P->src_y * P->nx + P->src_x;
+    const size_t rcv = (size_t)P->rcv_z * sxy + (size_t)P->rcv_y * P->nx + P->rcv_x;
+    for (int s = first_sample; s < first_sample + n_samples; ++s) {
+        for (int k = 0; k < tracks; ++k) {
+            const int t = order ? order[k] : k;
+            p[src] += in[(size_t)t * bufsize + s] * 0.1f;
+        }
+        for (int step = 0; step < P->steps_per_sample; ++step) fdtd_step(P, p, vx, vy, vz, fused);
+        float o = p[rcv] * 0.1f;
+        for (int t = 0; t < tracks; ++t) out[(size_t)t * bufsize + s] = o;
+    }
+}
+
 /* Track-dependent source and receiver cells — what the Metal port's inject/extract kernels
  * announce ("can be made track-dependent later", kernels_fdtd3d.metal:184,217) and never do:
  * track t adds 0.1f*in[t,s] into ITS source cell (tracks in order, so cells shared by several

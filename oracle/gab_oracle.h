@@ -147,6 +147,11 @@ void orc_fdtd_placeholder(const float* in, float* out, int tracks, int bufsize);
 void orc_fdtd(const orc_fdtd_params* P, float* p, float* vx, float* vy,
               float* vz, const float* in, float* out, int tracks, int bufsize,
               int first_sample, int n_samples, int fused);
+/* one order of the reference's atomicAdd at the source cell: samples accumulate into the cell track by track
+ * (order: a permutation of the tracks, NULL = ascending) */
+void orc_fdtd_trackwise(const orc_fdtd_params* P, float* p, float* vx, float* vy, float* vz,
+                        const float* in, float* out, int tracks, int bufsize, int first_sample,
+                        int n_samples, int fused, const int* order);
 void orc_fdtd_tracks(const orc_fdtd_params* P, float* p, float* vx, float* vy, float* vz,
                      const float* in, float* out, int tracks, int bufsize, int first_sample,
                      int n_samples, int fused, const int* src_xyz, const int* rcv_xyz);

@@ -41,3 +41,16 @@ def test_bench_launcher_propagates_a_failing_rank():
     # an impossible shard count for the dry run's bank makes a rank exit non-zero
     r = _run({"GAB_BENCH_DRYRUN_TRACKS": "0"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
+
+
+def test_bench_gpus_8_dry_run_at_c5_shapes():
+    """The driver's 8-GPU command shape on the CPU path: `bench.py --gpus 8` starts eight ranks, which rendezvous over
+    gloo and distribute BASELINE configs[4]'s bank (8192 channels x 4096 taps = 128 MiB) as 1024-channel slices at
+    global indices; every rank checks its slice against the formula at its global rows."""
+    r = _run({"GAB_BENCH_DRYRUN_TRACKS": "1024", "GAB_BENCH_DRYRUN_TAPS": "4096"},
+             "--gpus", "8", "--steps", "2", "--warmup", "1", "--ir-distribution", "slices")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 8 and d["config"]["channels_total"] == 8192 and d["config"]["channels_per_rank"] == 1024
+    assert d["config"]["taps"] == 4096 and d["config"]["ir_distribution"] == "slices"
+    assert d["config"]["ir_slices_match_global_bank"] is True

@@ -239,6 +239,42 @@ def test_fdtd_c4_as_baseline_states_it(gab, orc):
         assert np.abs(inner).max() > 1e-7
 
 
+def test_fdtd_c4_against_an_order_the_reference_atomics_can_produce(gab, orc):
+    """The source cell: the reference lets every track atomicAdd 0.1f*in[t,s] into p[src] (cuda/bench_fdtd3d.cu:101-120,
+    order unspecified), i.e. the samples accumulate INTO THE CELL one by one; the kernels (and orc_fdtd, which the
+    bit-exact tests pin) add the tracks' own sum once — a grouping no atomic order produces, at most the cell's last
+    bit apart per sample.  What that choice is worth over C4's 1002 steps, against two orders the reference CAN produce
+    (ascending and descending tracks; orc_fdtd_trackwise): both forms of the room within 1e-5 of the output's peak."""
+    import torch
+    n, T, B = 128, 8, 334
+    P = orc.fdtd_params(n)
+    G = gab.fdtd_default_params(n)
+    x = orc.Rand(1).bipolar(T * B)
+    refs = []
+    for order in (None, list(range(T - 1, -1, -1))):
+        grids = orc.fdtd_grids(P)
+        ref = np.zeros(T * B, np.float32)
+        orc.fdtd_trackwise(P, grids, x, ref, T, B, 0, B, fused=True, order=order)
+        refs.append((ref, grids[0].copy()))
+    xd = dev(x)
+    for form in ("auto", "step"):
+        plan = gab.FdtdPlan(G)
+        plan.set_form(form)
+        out = torch.zeros(T * B, device="cuda")
+        plan.process(xd, out, T, B, 0, B)
+        plan.status()
+        got, p_got = host(out), host(plan.pressure()).ravel()
+        for ref, p_ref in refs:
+            peak = float(np.abs(ref).max())
+            assert peak > 1e-6
+            assert float(np.abs(got - ref).max()) <= 1e-5 * peak, (form, float(np.abs(got - ref).max()) / peak)     # tolerance: 1e-5 of peak
+            ppeak = float(np.abs(p_ref).max())
+            assert float(np.abs(p_got - p_ref).max()) <= 1e-5 * ppeak, form
+        plan.close()
+    # the two atomic orders themselves differ from each other by no more than that
+    assert float(np.abs(refs[0][0] - refs[1][0]).max()) <= 1e-5 * float(np.abs(refs[0][0]).max())
+
+
 def test_fdtd_resident_launch_that_gives_up_fails_at_that_call():
     """Diagnostic build (workgroup 0 of the resident kernel never publishes: GAB_FDTD_RES_ABLATE=2), in a child
     process: the neighbours' bounded polls give up, the launch ENDS, THAT call's output is NaN in every sample,

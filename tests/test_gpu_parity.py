@@ -1024,6 +1024,45 @@ def test_dwg_mix_crowded_and_sparse_samples(gab, orc, variant):
     assert np.abs(ry).max() > 0 and np.count_nonzero(ry) > 10
 
 
+@pytest.mark.parametrize("n_wg,B,out_tracks", [(8192, 512, 8192), (2048, 2048, 2048), (3000, 100, 2500)])
+def test_dwg_large_bank_cells_kernel_appends_to_the_hit_lists(gab, orc, n_wg, B, out_tracks):
+    """Banks from 2 048 mixed waveguides on: the cells kernel's tap threads append to their samples' lists themselves
+    (dwg_cells_append_kernel; no gather launch), the mix kernel sorts and adds the lists in waveguide order and puts the
+    counters back to zero.  8 192 lines (the size the per-size
+    table prices), the longest buffer the staged input holds, and a mix over fewer tracks than there are lines — with
+    taps that are really reached (the reference's placement never is: SURVEY 8c) and write positions spread over the
+    lines; delay lines and mix bit-exact over four buffers on one workspace, then two calls on two streams at once (a
+    counter slot each)."""
+    import torch
+    ML = 2000
+    wg, x = orc.dwg_init(n_wg, B)
+    L = wg["length"].astype(np.int64)
+    wg["writePos"] = (np.arange(n_wg) * 13) % L
+    wg["outputTapPos"] = wg["inputTapPos"] = (wg["writePos"] + (np.arange(n_wg) % 5) * 3) % L
+    fwd_r, bwd_r = np.zeros(n_wg * ML, np.float32), np.zeros(n_wg * ML, np.float32)
+    fwd, bwd = torch.zeros(n_wg * ML, device="cuda"), torch.zeros(n_wg * ML, device="cuda")
+    wg_d = dev(wg.view(np.uint8))
+    for it in range(4):
+        y = host(gab.dwg(wg_d, fwd, bwd, dev(x), B, ML, out_tracks=out_tracks, variant=gab.DWG_ACCEL))
+        ry = orc.dwg(wg, fwd_r, bwd_r, x, B, ML, out_tracks=out_tracks)
+        assert np.array_equal(bits(y), bits(ry)), it
+        assert np.array_equal(bits(host(fwd)), bits(fwd_r)), it
+        assert np.array_equal(bits(host(bwd)), bits(bwd_r)), it
+    assert np.abs(ry).max() > 0 and np.count_nonzero(ry) >= 3
+    # two launches in flight on two streams: same state in, same bits out, twice
+    f2, b2 = fwd.clone(), bwd.clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        y1 = gab.dwg(wg_d, fwd, bwd, dev(x), B, ML, out_tracks=out_tracks, variant=gab.DWG_ACCEL)
+    with torch.cuda.stream(s2):
+        y2 = gab.dwg(wg_d, f2, b2, dev(x), B, ML, out_tracks=out_tracks, variant=gab.DWG_ACCEL)
+    torch.cuda.synchronize()
+    ry = orc.dwg(wg, fwd_r, bwd_r, x, B, ML, out_tracks=out_tracks)
+    assert np.array_equal(bits(host(y1)), bits(ry)) and np.array_equal(bits(host(y2)), bits(ry))
+    assert np.array_equal(bits(host(f2)), bits(fwd_r))
+
+
 @pytest.mark.parametrize("n,T,B,samples", [(20, 4, 16, 16), (52, 128, 512, 24), (33, 3, 8, 8),
                                           (128, 16, 8, 6),       # C4's grid, a few samples (LDS-halo kernel, 32 x 8)
                                           (100, 3, 6, 6),        # 32 x 8 tiles with a partial last tile row

@@ -223,3 +223,33 @@ def test_statistics(orc):
     assert abs(s.std_dev - np.std(lat, ddof=1)) < 1e-6
     assert abs(s.p95 - np.percentile(lat.astype(np.float64), 95)) < 1e-5
     assert abs(s.p99 - np.percentile(lat.astype(np.float64), 99)) < 1e-5
+
+
+def test_fdtd_source_cell_orders(orc):
+    """orc_fdtd_trackwise — one order of the reference's atomicAdd at the source cell (cuda/bench_fdtd3d.cu:101-120):
+    with ONE track it is orc_fdtd; with all tracks on the shared cells it is orc_fdtd_tracks (both accumulate into the
+    cell in ascending track order); against orc_fdtd's own grouping (the tracks' sum added once) any order stays within
+    rounding of the output's peak, and an order is really applied (a reversed one may change bits, never the scale)."""
+    n, T, B = 20, 8, 24
+    P = orc.fdtd_params(n)
+    x1 = orc.Rand(1).bipolar(B)
+    g1, g2 = orc.fdtd_grids(P), orc.fdtd_grids(P)
+    o1, o2 = np.zeros(B, np.float32), np.zeros(B, np.float32)
+    orc.fdtd(P, g1, x1, o1, 1, B, 0, B)
+    orc.fdtd_trackwise(P, g2, x1, o2, 1, B, 0, B)
+    assert np.array_equal(o1, o2) and np.array_equal(g1[0], g2[0])
+    x = orc.Rand(3).bipolar(T * B)
+    cells = lambda a, b, c: np.repeat(np.array([[a, b, c]], np.int32), T, axis=0)
+    ga, gb, gc, gd = (orc.fdtd_grids(P) for _ in range(4))
+    oa, ob, oc, od = (np.zeros(T * B, np.float32) for _ in range(4))
+    orc.fdtd_trackwise(P, ga, x, oa, T, B, 0, B)
+    orc.fdtd_tracks(P, gb, x, ob, T, B, 0, B, cells(P.src_x, P.src_y, P.src_z), cells(P.rcv_x, P.rcv_y, P.rcv_z))
+    assert np.array_equal(oa, ob) and np.array_equal(ga[0], gb[0])
+    orc.fdtd_trackwise(P, gc, x, oc, T, B, 0, B, order=list(range(T - 1, -1, -1)))
+    orc.fdtd(P, gd, x, od, T, B, 0, B)
+    peak = float(np.abs(od).max())
+    assert peak > 0
+    for o in (oa, oc):
+        assert float(np.abs(o - od).max()) <= 1e-5 * peak
+    with pytest.raises(AssertionError):
+        orc.fdtd_trackwise(P, orc.fdtd_grids(P), x, np.zeros(T * B, np.float32), T, B, 0, B, order=[0] * T)
