@@ -619,6 +619,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
+constexpr int kRtMaxGroups = 40;
 struct ConvRoundTrip {
     unsigned* stage;                  // [T*B] fine-grained device memory
     float* park;                      // [B*T] device memory
@@ -628,7 +629,8 @@ struct ConvRoundTrip {
     const unsigned* landed;           // pinned host: the epoch, once the host has seen the upload complete
     unsigned* error;                  // pinned host: nonzero if a wait ran out
     unsigned epoch;
-    int pairs_per_group, groups;
+    int groups;
+    unsigned bound[kRtMaxGroups + 1];   // group g = pairs [bound[g], bound[g + 1]): equal groups, the first and the last cut finer (see gab_conv_round_trip_init)
 };
 
 #ifdef GAB_ABLATE
@@ -656,7 +658,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     const int tid = threadIdx.x;
     const int q = blockIdx.x;                       // pairs in dispatch order: the copy lands them in that order too
     const int ta = 2 * q;
-    const int g = q / rt.pairs_per_group;
+    int g = 0;
+    while (q >= (int)rt.bound[g + 1]) ++g;          // (a scalar scan of at most kRtMaxGroups words)
     GAB_RT_STAMP_MIN(g, 0);
     cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
     using FA = fft::BlockFFT<kNA, 4, false>;
@@ -778,8 +781,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     // (zeroed by the last arriver before it announces), [2] the epoch once every member is parked.  A workgroup that
     // arrives early waits for [2] — bounded, and if it gives up it simply leaves: shares are claimed, not owned, and the
     // LAST arriver (who never waits) keeps claiming until none is left.  Nobody waits for a workgroup that has not started.
-    const int first = g * rt.pairs_per_group;
-    const int members = min(rt.pairs_per_group, (int)gridDim.x - first);
+    const int first = rt.bound[g];
+    const int members = (int)rt.bound[g + 1] - first;
     unsigned* const gw = rt.counters + 32 * g;
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(&gw[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2130,7 +2133,8 @@ struct gab_conv_plan {
     hipEvent_t rt_copy_ev = nullptr;
     hipEvent_t rt_done_ev = nullptr;      // the launch's own completion (what gab_conv_round_trip returns on)
     unsigned rt_epoch = 0;
-    int rt_groups = 0, rt_pairs_per_group = 0;
+    int rt_groups = 0;
+    unsigned rt_bound[gab::kRtMaxGroups + 1] = {};
     const void* rt_checked_out = nullptr;
     // gab_conv_engine_* (split cut): one resident launch fed through a doorbell
     float* eng_in = nullptr;            // fine-grained device memory: [ring][T*B], the producer writes it while the launch runs
@@ -2437,13 +2441,35 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, n));
     GAB_HIP_CHECK(hipMalloc(&p->rt_park, n * 4));
     int groups = 16;                                  // 64 channels = 256-byte rows at 1024 channels
+    int taper = 1;                                    // the first and the last group cut into quarter, quarter, half (round 5)
 #ifdef GAB_ABLATE
     if (getenv("GAB_RT_GROUPS")) groups = std::max(1, atoi(getenv("GAB_RT_GROUPS")));
+    if (getenv("GAB_RT_TAPER")) taper = atoi(getenv("GAB_RT_TAPER"));      // 0 equal groups, 1 both ends, 2 the head only, 3 the tail only
 #endif
     int ppg = (p->pairs + groups - 1) / groups;
     ppg += ppg & 1;                                   // whole float4 columns per row
-    p->rt_pairs_per_group = ppg;
-    p->rt_groups = (p->pairs + ppg - 1) / ppg;
+    // Groups are drained in the order the upload lands them.  The link's downward direction cannot start before the FIRST
+    // group is through, and after the LAST rows have landed nothing hides that group's transform and drain: both are cut
+    // finer (their rows are narrower — 64-byte pieces for 16 channels — but few).  Boundaries in pairs, every group even.
+    std::vector<int> sizes;
+    for (int at = 0; at < p->pairs; at += ppg) sizes.push_back(std::min(ppg, p->pairs - at));
+    auto cut = [&](int n, bool rising) {             // n pairs -> n/4, n/4, n/2 (rising) or n/2, n/4, n/4
+        std::vector<int> v;
+        if (n % 8 != 0 || n < 16) return std::vector<int>{n};
+        if (rising) v = {n / 4, n / 4, n / 2}; else v = {n / 2, n / 4, n / 4};
+        return v;
+    };
+    std::vector<int> fine;
+    for (size_t i = 0; i < sizes.size(); ++i) {
+        const bool head = i == 0 && (taper == 1 || taper == 2) && sizes.size() > 2;
+        const bool tail = i + 1 == sizes.size() && (taper == 1 || taper == 3) && sizes.size() > 2;
+        std::vector<int> v = head ? cut(sizes[i], true) : tail ? cut(sizes[i], false) : std::vector<int>{sizes[i]};
+        fine.insert(fine.end(), v.begin(), v.end());
+    }
+    if ((int)fine.size() > gab::kRtMaxGroups) throw std::runtime_error("gab_conv_round_trip: too many channel groups");
+    p->rt_groups = (int)fine.size();
+    p->rt_bound[0] = 0;
+    for (int g = 0; g < p->rt_groups; ++g) p->rt_bound[g + 1] = p->rt_bound[g] + (unsigned)fine[g];
     GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 1)));      // a 128-byte line per group
     GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 1)));
     GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
@@ -2530,7 +2556,8 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
         }
         gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
-                              epoch, p->rt_pairs_per_group, p->rt_groups};
+                              epoch, p->rt_groups, {}};
+        for (int g = 0; g <= p->rt_groups; ++g) rt.bound[g] = p->rt_bound[g];
         if (completion == 2)
             hipExtLaunchKernelGGL(gab::conv_round_trip_kernel, dim3(p->pairs), dim3(gab::kThreads), 0, s, nullptr, p->rt_done_ev, 0,
                                   rt, p->hist, (const float4*)p->pmA, (const float4*)p->pmB, (const gab::fft::cf*)p->tw, p->tracks, p->head);
