@@ -427,7 +427,11 @@ struct BlockFFT {
         // are multiples of R = 2^SH (or, in pass 0, the R values of a thread are
         // contiguous).  Recomputing Pad() per element costs ~3 integer VALU ops per
         // access, ~100 per radix-16 pass, in a kernel that is VALU-bound.
+#ifdef GAB_FFT_NOPAD_READS                                      // EXPERIMENT builds only (wrong results): what the linear reads' two-way bank
+        const unsigned rd_base = t;                             // conflicts cost — the same reads without the pad term are conflict-free
+#else
         const unsigned rd_base = t + (t >> SH);                 // Pad(t + r*NT) = rd_base + r*RD
+#endif
         constexpr unsigned RD = NT + (NT >> SH);
         cf* buf = ldsA;
         cf* other = ldsB;
@@ -568,7 +572,11 @@ struct WaveFFT1024 {
         }
         __builtin_amdgcn_wave_barrier();
         hook(0);
+#ifdef GAB_FFT_NOPAD_READS
+        const unsigned rb = lane;
+#else
         const unsigned rb = lane + (lane >> 4);         // Pad(lane + 64 r) = rb + 68 r
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = img[rb + 68 * r];
         {

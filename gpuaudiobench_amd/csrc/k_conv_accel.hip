@@ -955,7 +955,11 @@ __device__ __forceinline__ void conv_split_batch_resident(
     __syncthreads();
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GAB_FFT_NOPAD_READS                                         // EXPERIMENT builds only (wrong results): gab_fft.hpp
+    const unsigned rb = (unsigned)lane;
+#else
     const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+#endif
     auto gate = [&](int) -> int { return n_buffers; };    // (the engine's doorbell gate stands here in conv_split_engine_resident)
     // buffer nb of the launch; callers walk the buffers with next_slot()
     auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
