@@ -51,7 +51,7 @@ CLOCK_WARM_STEPS = 500          # untimed, besides --warmup: ~0.2 s of the same 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 PARITY_CHANNELS = 16            # sampled per checked buffer
 PARITY_TOL = 1e-5               # of the stream's peak (north_star: 1e-5 relative for float DSP)
-TRAFFIC_SOURCE = "profiles/r04_conv_batch_pmc_means.json"
+TRAFFIC_SOURCE = "profiles/r05_conv_batch_pmc_means.json"
 
 
 def cpu_threads():
@@ -316,7 +316,11 @@ def main():
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GAB_")},
         },
         "roofline": {
+            # `bound` names the roofline the contract prices against (algorithmic bytes over the 8 TB/s HBM peak);
+            # what actually limits the kernel is `limited_by` / `bound_measured`: not memory
             "bound": "hbm",
+            "limited_by": "instruction issue and latency of the far role's transform chain (one wave per SIMD beside a near wave), not HBM: "
+                          "see bound_measured and hbm_frac_measured",
             "kernel": "conv_split_batch_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

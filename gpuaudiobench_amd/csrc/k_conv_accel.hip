@@ -2540,10 +2540,6 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         // h_in is read by the copy from the moment of this call: it must be complete on the host (or, for device memory,
         // on the device) by then — the upload runs on the plan's own stream and is NOT ordered behind work queued on `stream`.
         bool streamed = true;
-        bool may_stream_pageable = false;
-#ifdef GAB_ABLATE
-        if (getenv("GAB_RT_STREAM_PAGEABLE")) may_stream_pageable = true;      // diagnostic builds: the form the incident was met with
-#endif
         // put the stage back to all-sentinel and the upload stream to rest (after anything that may have left words behind)
         auto rearm_stage = [&]() {
             (void)hipStreamSynchronize(s);
@@ -2551,7 +2547,7 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, (size_t)p->tracks * p->bufsize);
             (void)hipDeviceSynchronize();
         };
-        if (upload && !may_stream_pageable && !mapped(h_in)) {
+        if (upload && !mapped(h_in)) {
             GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
             GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
             __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);

@@ -1,5 +1,5 @@
 """Mean per launch of every counter rocprofv3 collected for one kernel, from the
-<dir>/pmc_*_counter_collection.csv files of separate --pmc passes (tools/profile_r03.sh).
+<dir>/pmc_*_counter_collection.csv files of separate --pmc passes (tools/profile_r05.sh).
 
     python tools/pmc_means.py <dir> <kernel name part> <algorithmic bytes per launch> [skip first N launches] > out.json
 
