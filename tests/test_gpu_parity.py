@@ -665,6 +665,62 @@ def test_conv_accel_engine_one_buffer_in_flight(gab, orc, T):
     b.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_conv_accel_engine_bursts_of_any_shape_walk_one_history(gab, orc, seed):
+    """The engine's launch is a sequence of bursts whose boundaries the DOORBELL decides (gab_conv_engine_submit: how many
+    buffers, with or without the flush rung, and when) — and workgroups need not even agree on them.  A seeded random
+    producer: bursts of 1..9 buffers, flushed or not (a burst without the rung is finished by the next one's), pauses of
+    0..3 ms in between, slots reused as soon as their buffer has come back; every output bit for bit what one
+    gab_conv_process launch per buffer gives, and ordinary launches continue the stream after the stop."""
+    import time
+    import torch
+    rng = np.random.default_rng(seed)
+    T, B, L, R = 64, 512, 4096, 16
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    N = 120
+    xs = [orc.noise(T * B, seed=7000 + 131 * seed + i) for i in range(N + 1)]
+    want = [host(a.process(dev(x), mode=gab.CONV_STREAMING)) for x in xs]
+    side = torch.cuda.Stream()
+    in_ring, out_ring = b.engine_start(R, stream=side)
+    cur = torch.cuda.current_stream()
+    taken = 0
+
+    def take_until(k_done):
+        nonlocal taken
+        while taken < k_done:
+            got = host(out_ring[taken % R])
+            assert np.array_equal(bits(got), bits(want[taken])), "buffer %d" % taken
+            taken += 1
+
+    published = 0
+    while published < N:
+        n = int(min(N - published, rng.integers(1, 10)))
+        flush = bool(rng.integers(0, 2)) or published + n == N      # the last burst must be finished by somebody
+        # slots of this burst must be free: their previous buffers taken
+        if published + n - taken > R:
+            b.engine_submit(0, flush=True)                           # finish what is pending, then collect it
+            b.engine_wait(published, timeout=8.0)
+            take_until(published)
+        for j in range(n):
+            in_ring[(published + j) % R].copy_(dev(xs[published + j]))
+        cur.synchronize()
+        b.engine_submit(n, flush=flush)
+        published += n
+        if flush and rng.integers(0, 2):
+            b.engine_wait(published, timeout=8.0)
+            take_until(published)
+        time.sleep(float(rng.integers(0, 4)) * 1e-3)
+    b.engine_wait(N, timeout=8.0)
+    take_until(N)
+    b.engine_stop()
+    assert np.array_equal(bits(host(b.process(dev(xs[N]), mode=gab.CONV_STREAMING))), bits(want[N]))
+    a.close()
+    b.close()
+
+
 def test_conv_accel_engine_feed_matches_batch_launches_and_carries_history(gab, orc):
     """gab_conv_engine_feed on resident rings (what bench.py times): 3 x 16 buffers, one per ring of the doorbell with
     at most eight in flight, leave in the output ring what three batch launches of 16 leave; ordinary launches after
