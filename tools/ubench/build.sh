@@ -11,4 +11,6 @@ $H -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o tools/ubench/bin/valu
 $H -O3 --offload-arch=gfx950 tools/ubench/link_duplex.hip -o tools/ubench/bin/link_duplex
 $H -O3 --offload-arch=gfx950 tools/ubench/link_modes.hip -o tools/ubench/bin/link_modes
 $H -O3 --offload-arch=gfx950 tools/ubench/dep_chain.hip -o tools/ubench/bin/dep_chain
+
+$H -O2 --offload-arch=gfx950 tools/ubench/prearmed_copy.hip -o tools/ubench/bin/prearmed_copy
 ls -la tools/ubench/bin
