@@ -450,7 +450,7 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
         "frac": alg / one_us / 1e3 / HBM_PEAK_GBS, "launches": 4000}
 
     # ---- the same buffers ARRIVING one at a time at a resident launch (gab_conv_engine_*): the host rings the doorbell once
-    # per buffer and keeps at most `ahead` in flight; the ring is the resident batch.  HIP events on the engine's own
+    # per buffer and keeps at most `ahead` in flight; the ring is the resident batch.  HIP events around start .. stop on a side
     # stream around the whole launch; the output ring checked bit for bit against batch launches over the same buffers.
     ahead, passes = 16, 64
     # The engine's ring is HALF a step (64 slots: 128 MiB in, 128 MiB out), and every batch launch of this leg — the clock

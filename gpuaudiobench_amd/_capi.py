@@ -108,6 +108,7 @@ PROTOTYPES = {
     "gab_conv_engine_publish": (_I, [_P, _I]),
     "gab_conv_engine_submit": (_I, [_P, _I, _I]),
     "gab_conv_engine_wait": (_I, [_P, _I, C.c_double]),
+    "gab_conv_engine_running": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_engine_completed": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_engine_feed": (_I, [_P, _I, _I]),
     "gab_conv_engine_feed_one_in_flight": (_I, [_P, _I, _P]),

@@ -2149,7 +2149,11 @@ struct gab_conv_plan {
     bool eng_running = false;
     unsigned eng_published = 0;
     unsigned eng_seen_completed = 0;
-    hipStream_t eng_stream = nullptr;
+    hipStream_t eng_stream = nullptr;    // the stream the resident launch is on: the plan's own (below)
+    hipStream_t eng_own_stream = nullptr; // created at the first start, at the HIGHEST priority: the runtime maps streams onto a few hardware
+                                          // queues per priority, and anything that shares a queue with a resident launch stands behind it until
+                                          // the stop (round 5: a copy on the default stream did, and the engine starved for its own doorbell)
+    hipEvent_t eng_ev = nullptr;
     // uniform partitions (conv_uniform_kernel): other power-of-two buffer sizes / longer responses
     bool uniform = false;
     int uJ = 0, uS = 0, ring_len = 0;
@@ -2275,6 +2279,8 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->eng_done) (void)hipFree(p->eng_done);
     if (p->eng_words) (void)hipHostFree(p->eng_words);
     if (p->rt_copy_ev) (void)hipEventDestroy(p->rt_copy_ev);
+    if (p->eng_ev) (void)hipEventDestroy(p->eng_ev);
+    if (p->eng_own_stream) (void)hipStreamDestroy(p->eng_own_stream);
     if (p->rt_done_ev) (void)hipEventDestroy(p->rt_done_ev);
     if (p->rt_copy_stream) (void)hipStreamDestroy(p->rt_copy_stream);
     delete p;
@@ -2639,6 +2645,12 @@ int gab_conv_engine_rings(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
         if (p->eng_running) return gab::bad_arg("gab_conv_engine_rings: the plan's engine is running");
         if (ring_buffers < 3 || ring_buffers > 4096) return gab::bad_arg("gab_conv_engine_rings: ring_buffers must be 3..4096");
         const size_t n = (size_t)p->tracks * p->bufsize;
+        if (!p->eng_own_stream) {                     // the launch's own stream (see gab_conv_plan): made here, ahead of any timed start
+            int lo = 0, hi = 0;                       // (numerically lower = higher priority)
+            GAB_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            GAB_HIP_CHECK(hipStreamCreateWithPriority(&p->eng_own_stream, hipStreamNonBlocking, hi));
+            GAB_HIP_CHECK(hipEventCreateWithFlags(&p->eng_ev, hipEventDisableTiming));
+        }
         if (p->eng_ring != ring_buffers) {
             if (p->eng_in) { (void)hipFree(p->eng_in); p->eng_in = nullptr; }
             if (p->eng_out) { (void)hipFree(p->eng_out); p->eng_out = nullptr; }
@@ -2675,7 +2687,11 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
                                      std::to_string(p->tracks) + " channels — shard the channels (one engine per device) or use gab_conv_process_batch").c_str());
         }
         if (int rc = gab_conv_engine_rings(p, ring_buffers, d_in_ring, d_out_ring)) return rc;
-        hipStream_t s = gab::as_stream(stream);
+        hipStream_t caller = gab::as_stream(stream);
+        // the launch goes on the plan's own stream, behind whatever the caller's stream holds now
+        GAB_HIP_CHECK(hipEventRecord(p->eng_ev, caller));
+        GAB_HIP_CHECK(hipStreamWaitEvent(p->eng_own_stream, p->eng_ev, 0));
+        hipStream_t s = p->eng_own_stream;
         const size_t prog_words = 2 * (size_t)(p->tracks / 4) + 32;        // + the relay word on a line of its own
         if (!p->eng_done) GAB_HIP_CHECK(hipMalloc(&p->eng_done, prog_words * sizeof(unsigned)));
         if (!p->eng_words) {
@@ -2717,6 +2733,16 @@ int gab_conv_engine_submit(gab_conv_plan* p, int n_more, int flush) {
 }
 
 int gab_conv_engine_publish(gab_conv_plan* p, int n_more) { return gab_conv_engine_submit(p, n_more, 0); }
+
+int gab_conv_engine_running(gab_conv_plan* p, int* running) {
+    if (!p || !running) return gab::bad_arg("gab_conv_engine_running: null argument");
+    *running = 0;
+    if (!p->eng_running) return GAB_OK;
+    const hipError_t q = hipStreamQuery(p->eng_stream);            // the launch is the only thing on the plan's own stream
+    (void)hipGetLastError();
+    *running = q == hipErrorNotReady ? 1 : 0;
+    return GAB_OK;
+}
 
 int gab_conv_engine_wait(gab_conv_plan* p, int count, double timeout_seconds) {
     return gab::guarded([&]() -> int {

@@ -271,6 +271,12 @@ class ConvPlan:
         """Spins until `count` buffers are reported complete (gab_conv_engine_wait)."""
         check(lib.gab_conv_engine_wait(self._h, count, float(timeout)))
 
+    def engine_running(self):
+        """True while the resident launch is still on the device (gab_conv_engine_running)."""
+        v = C.c_int(0)
+        check(lib.gab_conv_engine_running(self._h, C.byref(v)))
+        return bool(v.value)
+
     def engine_completed(self):
         v = C.c_int(0)
         check(lib.gab_conv_engine_completed(self._h, C.byref(v)))

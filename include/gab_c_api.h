@@ -243,7 +243,9 @@ int gab_conv_newest_block(gab_conv_plan* plan, float* d_out, gab_stream_t stream
  *             [slot][B*T] sample-major out; ordinary device memory that the launch reads with system-scope loads and
  *             writes with write-through stores: COPY ENGINES may write and read them while the launch runs — kernels
  *             cannot: at 1024 channels the engine holds every compute unit until it stops);
- *   start     the same rings, and launches on `stream`, which the launch occupies until stop;
+ *   start     the same rings, and launches BEHIND what `stream` holds at the call, on a stream of the plan's own at the
+ *             highest priority (the runtime maps streams onto a few hardware queues per priority; work that shared a queue with
+ *             the resident launch would stand behind it until stop — at normal priority a copy on another stream did);
  *   publish   after buffer k has been written to slot k % ring_buffers: the doorbell count goes up by n_more;
  *   submit    publish with a rung: flush != 0 says "finish what is published, do not wait for more" — the real-time form,
  *             ONE buffer in flight: a period then runs buffer k although k + 1 is not there (it requests nothing for it),
@@ -261,7 +263,10 @@ int gab_conv_newest_block(gab_conv_plan* plan, float* d_out, gab_stream_t stream
  *             `ahead` (6 <= ahead < ring_buffers) in front of `completed`;
  *   stop      rings the stop bit, waits for the launch to end (every published buffer is finished), carries the
  *             history on for the next gab_conv_process / batch / engine.
- * The device is the engine's while it runs (256 workgroups at 1024 channels): other kernels queue behind it, and every
+ * The device is the engine's while it runs (256 workgroups at 1024 channels): other kernels queue behind it — and with
+ * FEWER channels a kernel on another stream may still wait until stop: the runtime maps streams onto a few hardware
+ * queues, and a kernel (a device-to-device copy is one) that lands on the engine's queue stands behind the resident
+ * launch.  Only copy ENGINES (pinned host <-> device copies) are sure to move the rings while the launch runs.  Every
  * workgroup of the engine must be resident at once: start refuses a plan with more channels than 4 x the workgroups the
  * device holds (1024 channels on MI355X; more channels: one engine per device over channel shards).  If the
  * doorbell does not move for about two seconds the launch ends by itself and stop / feed return GAB_ERR_RUNTIME.      */
@@ -270,6 +275,8 @@ int gab_conv_engine_start(gab_conv_plan* plan, int ring_buffers, float** d_in_ri
 int gab_conv_engine_publish(gab_conv_plan* plan, int n_more);
 int gab_conv_engine_submit(gab_conv_plan* plan, int n_more, int flush);
 int gab_conv_engine_wait(gab_conv_plan* plan, int count, double timeout_seconds);
+/* 1 while the resident launch is still on the device (it ends by itself if the doorbell stops moving; stop still has to be called) */
+int gab_conv_engine_running(gab_conv_plan* plan, int* running);
 int gab_conv_engine_completed(gab_conv_plan* plan, int* completed);
 int gab_conv_engine_feed(gab_conv_plan* plan, int n_buffers, int ahead);
 int gab_conv_engine_feed_one_in_flight(gab_conv_plan* plan, int n_buffers, float* latency_us);
