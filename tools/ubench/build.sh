@@ -13,4 +13,5 @@ $H -O3 --offload-arch=gfx950 tools/ubench/link_modes.hip -o tools/ubench/bin/lin
 $H -O3 --offload-arch=gfx950 tools/ubench/dep_chain.hip -o tools/ubench/bin/dep_chain
 
 $H -O2 --offload-arch=gfx950 tools/ubench/prearmed_copy.hip -o tools/ubench/bin/prearmed_copy
+$H -O3 --offload-arch=gfx950 -ffp-contract=off -I gpuaudiobench_amd/csrc -I include tools/ubench/far_transform.hip -o tools/ubench/bin/far_transform
 ls -la tools/ubench/bin
