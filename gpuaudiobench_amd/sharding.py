@@ -52,6 +52,9 @@ def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=
     if dist is None:                # no process group: one rank makes its own bank
         return torch.from_numpy(harness.conv_accel_ir(ir_len, hi - lo, lo, total_tracks)).to(device)
     if distribution == "slices":
+        final_device = device
+        if dist.get_backend() == "gloo":          # gloo scatters and sends host tensors only (CPU tests, the one-GPU rehearsal)
+            device = torch.device("cpu")
         mine = torch.empty((hi - lo) * ir_len, dtype=torch.float32, device=device)
         parts = None
         if rank == src:
@@ -71,7 +74,7 @@ def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=
                     q.wait()
             else:
                 dist.recv(mine, src=src)
-        return mine.view(hi - lo, ir_len)
+        return mine.view(hi - lo, ir_len).to(final_device)
     if distribution != "broadcast":
         raise ValueError("distribution must be 'broadcast' or 'slices'")
     bank = torch.empty(total_tracks * ir_len, dtype=torch.float32, device=device)

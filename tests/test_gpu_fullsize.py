@@ -411,25 +411,31 @@ def test_fdtd_non_cubic_rooms_bit_exact(gab, orc, nx, ny, nz, samples):
     plan.close()
 
 
-def test_bench_under_a_launcher_walks_the_rccl_path_on_one_gpu():
+@pytest.mark.parametrize("ranks,distribution", [(1, "broadcast"), (1, "slices"), (2, "slices")])
+def test_bench_under_a_launcher_walks_the_rccl_path_on_one_gpu(ranks, distribution):
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the rank creates the RCCL
-    process group (backend nccl), broadcasts the impulse-response bank through it, meets the barriers and
-    all-reduces the timing — the N > 1 code path with one rank, on the hardware the box has — and the
-    line still carries the in-run parity check."""
+    process group (backend nccl), distributes the impulse-response bank through it (as a broadcast, or as per-rank
+    slices), meets the barriers and all-reduces the timing — the N > 1 code path with one rank, on the hardware the
+    box has — and the line still carries the in-run parity check.  Two ranks: GAB_BENCH_REHEARSE=1, both on device 0
+    over gloo (the rate means nothing then, the line says so): rank 1's rows of the bank arrive by a send, its input rows
+    and the parity check at GLOBAL channel indices."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ranks > 1:
+        env["GAB_BENCH_REHEARSE"] = "1"
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--clock-warm-steps", "5",
-                        "--no-side-legs", "--no-cpu-baseline"],
+                        "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--clock-warm-steps", "5",
+                        "--no-side-legs", "--no-cpu-baseline", "--ir-distribution", distribution],
                        capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "nccl"
+    assert d["n_gpus"] == ranks and d["config"]["collective_backend"] == ("nccl" if ranks == 1 else "gloo")
+    assert d["config"]["ir_distribution"] == distribution and d["config"]["channels_total"] == 1024 * ranks
     assert d["config"]["ir_broadcast_ms"] is not None and d["config"]["ir_broadcast_ms"] >= 0
     assert d["parity_checked"]["ok"] is True and d["value"] > 0
