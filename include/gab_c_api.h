@@ -144,7 +144,10 @@ typedef struct {
  * small and would be written past its end.                                                                */
 size_t gab_dwg_workspace_bytes(int n_waveguides, int bufsize);
 /* Updates the two delay-line banks (n_wg x max_len) in place and writes the
- * mono mix d_out[bufsize], summed over waveguides in index order.            */
+ * mono mix d_out[bufsize], summed over waveguides in index order.
+ * GAB_DWG_ACCEL with 2048 or more mixed waveguides and bufsize <= 2048 keeps its per-sample hit counters in one of 16
+ * slots of the library (not in d_workspace: they must be zero before the call's first append), picked round robin:
+ * at most 16 such calls may be in flight at once per device (calls on one stream never are).                     */
 int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd,
             const float* d_in, float* d_out, void* d_workspace, int n_waveguides,
             int bufsize, int max_len, int out_tracks, int variant,
