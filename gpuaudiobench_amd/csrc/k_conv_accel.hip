@@ -921,7 +921,7 @@ struct ConvEngine {
     int ring;                     // buffers in the input and output rings (>= 3)
     int poll_every_period;        // 1; diagnostic builds may turn it off (the word is then read only when the engine stalls)
 };
-constexpr int kEnginePollLimit = 1 << 21;      // x ~1 us: about two seconds without the word moving
+constexpr int kEnginePollLimit = 3 << 20;      // x ~0.7-2 us a look: two to six seconds without the word moving
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // experiments only (GAB_EXTRA_FLAGS=-DGAB_ENGV=bits, a build of its own): 1 no progress words / aggregator, 2 plain output
@@ -1297,8 +1297,11 @@ __device__ __forceinline__ void conv_split_engine_resident(
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
-    // WORKGROUP 0's first inverse wave is the aggregator: every inverse wave's count of finished buffers (8 per lane, sc1
-    // loads), the minimum into `completed` (pinned host word) — from the period loop and from the idle loop below
+    // The aggregator — the first inverse wave of workgroup 1 (workgroup 0 where there is only one) — takes every inverse wave's count
+    // of finished buffers (8 per lane, sc1 loads) and writes the minimum into `completed` (pinned host word), from the period loop
+    // and from the idle loop below.  Not workgroup 0: that one's idle loop reads the doorbell over the link, two microseconds a look,
+    // and a count that waits behind such a look reaches the host that much later.
+    const bool aggregator = blockIdx.x == (gridDim.x > 1 ? 1u : 0u);
     unsigned reported = 0;                                            // (meaningful in that wave only)
     auto aggregate_request = [&](u4& a, u4& b) {
         const auto srd = __builtin_amdgcn_make_buffer_rsrc(eng.progress, 0, (int)(8u * gridDim.x), 0x00020000);
@@ -1346,11 +1349,11 @@ __device__ __forceinline__ void conv_split_engine_resident(
                     int tries = 0;
                     for (;;) {
                         u4 pa, pb;
-                        if (blockIdx.x == 0 && !GAB_EABL(1)) aggregate_request(pa, pb);
+                        if (aggregator && !GAB_EABL(1)) aggregate_request(pa, pb);
                         unsigned mine = 0;
                         if (lane == 0) mine = read_door();
                         v = __builtin_amdgcn_readfirstlane(mine);
-                        if (blockIdx.x == 0 && !GAB_EABL(1)) aggregate_report(pa, pb);
+                        if (aggregator && !GAB_EABL(1)) aggregate_report(pa, pb);
                         const int p2 = (int)(v & 0x3fffffffu);
                         if (p2 >= nb + 2 || (v >> 31) || (((v >> 30) & 1u) && p2 >= nb + 1)) break;
                         if (++tries > kEnginePollLimit) {             // the producer is gone: stop here, say so
@@ -1361,7 +1364,7 @@ __device__ __forceinline__ void conv_split_engine_resident(
                             v = 0x80000000u | (unsigned)(p2 < nb ? p2 : nb);
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(20);
+                        __builtin_amdgcn_s_sleep(6);                      // (~0.2 us between looks: with 20, a quarter of a microsecond more from doorbell to count)
                     }
                     if (lane == 0) s_door[nb & 1] = v;
                 }
@@ -1685,11 +1688,11 @@ __device__ __forceinline__ void conv_split_engine_resident(
                 if (tid == kPoller && eng.poll_every_period)      // asked now, needed at the period's end
                     door_next = blockIdx.x == 0 ? __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                                 : __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) aggregate_request(prog_a, prog_b);
+                if (aggregator && pr == 0 && !GAB_EABL(1)) aggregate_request(prog_a, prog_b);
             }
             auto close_period = [&]() {                           // before the closing barrier
                 if constexpr (ENGINE) {
-                    if (blockIdx.x == 0 && pr == 0 && !GAB_EABL(1)) aggregate_report(prog_a, prog_b);
+                    if (aggregator && pr == 0 && !GAB_EABL(1)) aggregate_report(prog_a, prog_b);
                     if (tid == kPoller) {
                         s_door[(nb + 1) & 1] = door_next;
                         if (blockIdx.x == 0 && eng.poll_every_period)
