@@ -15,8 +15,8 @@ step to the next (the stream never restarts).  Results are bit-identical to one
 gab_conv_process launch per buffer (tests/), whose rate is reported beside `value`.
 
 With N > 1 every rank owns a 1024-channel shard of an N*1024-channel job: rank 0
-generates the whole impulse-response bank, it is broadcast over RCCL/xGMI once,
-each rank transforms its slice; there is no per-buffer collective (channels are
+generates the whole impulse-response bank, it is broadcast over RCCL/xGMI once (or, --ir-distribution slices,
+sent as per-rank rows), each rank transforms its slice; there is no per-buffer collective (channels are
 independent), so scaling is weak.  A plain `python bench.py --gpus N` starts the N
 ranks itself (torch.distributed.run) before touching any GPU and relays rank 0's line.
 
@@ -26,8 +26,11 @@ One JSON line on rank 0:
                    launch stream over the timed region), against 8 TB/s HBM
   parity_checked = after the timed region: sampled channels of the last step's first and last
                    buffer against the float64 direct form (the CPU oracle); mismatch => exit 1
-  round_trip     = (config) p50 / p95 of one buffer pinned host -> GPU -> pinned host through gab_conv_round_trip,
-                   against the link floor measured in the same run
+  round_trip     = (config) p50 / p95 of one buffer pinned host -> GPU -> pinned host through gab_conv_round_trip
+                   (returns on the launch's own completion event), against the link floor measured in the same run
+  one_buffer_per_doorbell = (config) the resident engine: pipelined rate, and under in_flight_1 the time from doorbell
+                   to `completed` with ONE buffer in flight (the reference's iteration), back to back and paced
+  a bit-identity flag of either leg that is False => exit 1
   cpu_baseline   = the CPU oracle (the reference golden extended with history), timed on a
                    bounded sample of the same workload on this box's cores (N = 1 only)
 """
