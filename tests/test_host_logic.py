@@ -260,3 +260,32 @@ def test_private_rand_streams_are_the_platforms_and_can_be_entered_anywhere():
         part = np.empty(500, np.int32)
         assert _capi.lib.gab_glibc_rand(seed, 1234, part.ctypes.data_as(C.c_void_p), part.size) == 0
         assert np.array_equal(part, ref[1234:1734])
+
+
+def test_round_trip_mismatch_report_classifies_each_kind_of_wrong_word():
+    """tests/rt_diag.py (the report a failing round-trip comparison prints) on synthetic failures: a row that had not
+    arrived (NaN pieces in an otherwise right pair), a pair poisoned by a sentinel taken for a sample (all NaN), a stale
+    output word, a consumed block that differs from h_in (with the sentinel and with the previous call's word) — and
+    nothing to say when the bits agree."""
+    import numpy as np
+    import rt_diag
+    T, B = 16, 512
+    rng = np.random.default_rng(5)
+    want = rng.standard_normal((B, T)).astype(np.float32)
+    h_in = rng.standard_normal((T, B)).astype(np.float32)
+    prev_in = rng.standard_normal((T, B)).astype(np.float32)
+    prev_out = rng.standard_normal((B, T)).astype(np.float32)
+    assert rt_diag.classify(want, want.copy(), T, B, prev_out=prev_out, h_in=h_in, consumed=h_in.copy(), prev_in=prev_in) == ""
+    got = want.copy()
+    got[7, 4:8] = np.nan                                   # a 16-byte piece of one row never arrived
+    got[:, 10:12] = np.nan                                 # channel pair 5 poisoned
+    got[100, 0] = prev_out[100, 0]                         # a stale word
+    consumed = h_in.copy()
+    consumed.view(np.uint32)[3, 17] = rt_diag.SENTINEL     # the kernel took the sentinel for a sample
+    consumed[9, 200] = prev_in[9, 200]                     # ... and a word of the previous call's input
+    text = rt_diag.classify(want, got, T, B, prev_out=prev_out, h_in=h_in, consumed=consumed, prev_in=prev_in, label="call 3")
+    assert text.startswith("call 3:") and "poisoned-pair: [5]" in text and "missing-row: 4" in text
+    assert "stale-output (finite, equal to the previous call's output there): 1 of 1" in text
+    assert "differs from h_in in 2 words" in text and "the sentinel: 1" in text and "previous call's input word: 1" in text
+    # outputs right but the consumed block wrong is still a finding
+    assert "consumed block differs" in rt_diag.classify(want, want.copy(), T, B, h_in=h_in, consumed=consumed)
