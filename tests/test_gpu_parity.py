@@ -659,7 +659,16 @@ def test_conv_accel_engine_one_buffer_in_flight(gab, orc, T):
         b.engine_wait(k + 1, timeout=8.0)
         take(k)
         k += 1
+    with pytest.raises(gab.GabError):
+        b.engine_wait(k + 1, timeout=1.0)              # more than has been published
+    with pytest.raises(gab.GabError):
+        b.engine_submit(-1)
+    assert b.engine_running()
     b.engine_stop()
+    assert not b.engine_running()
+    for call in (lambda: b.engine_submit(1), lambda: b.engine_feed_one_in_flight(1)):
+        with pytest.raises(gab.GabError):              # no running engine
+            call()
     assert np.array_equal(bits(host(b.process(dev(xs[k]), mode=gab.CONV_STREAMING))), bits(want[k]))
     a.close()
     b.close()
