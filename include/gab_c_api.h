@@ -272,7 +272,7 @@ int gab_conv_newest_block(gab_conv_plan* plan, float* d_out, gab_stream_t stream
  * launch.  Only copy ENGINES (pinned host <-> device copies) are sure to move the rings while the launch runs.  Every
  * workgroup of the engine must be resident at once: start refuses a plan with more channels than 4 x the workgroups the
  * device holds (1024 channels on MI355X; more channels: one engine per device over channel shards).  If the
- * doorbell does not move for about two seconds the launch ends by itself and stop / feed return GAB_ERR_RUNTIME.      */
+ * doorbell does not move for a few seconds (2-6) the launch ends by itself and stop / feed / wait return GAB_ERR_RUNTIME. */
 int gab_conv_engine_rings(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring);
 int gab_conv_engine_start(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring, gab_stream_t stream);
 int gab_conv_engine_publish(gab_conv_plan* plan, int n_more);
