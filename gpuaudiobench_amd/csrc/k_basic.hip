@@ -458,7 +458,15 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
                 (void)hipGetLastError();
                 streamed = false;
             }
-            GAB_HIP_CHECK(hipMemcpyAsync(p->stage, h_in, sizeof(float) * (size_t)in_size, hipMemcpyHostToDevice, p->copy_stream));
+            // in pieces below the runtime's engine-packet limit (4 MiB - 1 BYTES), each a multiple of four bytes: the word that
+            // straddles a packet boundary of ONE big copy lands in two pieces, and the kernel takes words as they stop being
+            // the sentinel (k_conv_accel.hip, kRtUploadPiece; profiles/r05_incident_torn_word.txt)
+            {
+                const size_t bytes = sizeof(float) * (size_t)in_size, piece = (size_t(4) << 20) - 256;
+                for (size_t off = 0; off < bytes; off += piece)
+                    GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->stage) + off, reinterpret_cast<const char*>(h_in) + off,
+                                                 std::min(piece, bytes - off), hipMemcpyHostToDevice, p->copy_stream));
+            }
             if (!streamed) GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
         }
         if (in_size > out_size) {

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 //         signal (HIP: everything a kernel wrote is visible to the host once the launch's event has completed).
 // Same operations in the same order as conv_overlap_save_kernel<true, true>: bit-identical to device-buffer launches.
 constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
+constexpr size_t kRtUploadPiece = (size_t(4) << 20) - 256;   // bytes per engine copy of an upload that a kernel consumes as it lands (below the runtime's 4 MiB - 1 packet limit, a multiple of 256)
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
 constexpr int kRtMaxGroups = 40;
@@ -2556,13 +2557,24 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, (size_t)p->tracks * p->bufsize);
             (void)hipDeviceSynchronize();
         };
+        // The engine copy goes out in pieces of kRtUploadPiece bytes, a multiple of four: the runtime cuts a copy into engine
+        // packets of at most 4 MiB - 1 BYTES, so in one big copy the word that straddles a packet boundary is written in two
+        // pieces — and a consumer that takes a word the moment it differs from the sentinel took three landed bytes with the
+        // sentinel's fourth (round 5, caught by the self-classifying stress at 2052 channels: word 1 048 575, bytes 4 194 300 -
+        // 4 194 303, consumed fff4b08e for bef4b08e; the r04 incident at 8192 channels has three such words:
+        // profiles/r05_incident_torn_word.txt).  Within a packet the engine writes whole aligned bursts.
+        auto upload_pieces = [&]() {
+            for (size_t off = 0; off < bytes; off += gab::kRtUploadPiece)
+                GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->rt_stage) + off, reinterpret_cast<const char*>(h_in) + off,
+                                             std::min(gab::kRtUploadPiece, bytes - off), hipMemcpyHostToDevice, p->rt_copy_stream));
+        };
         if (upload && !mapped(h_in)) {
-            GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+            upload_pieces();
             GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
             __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);
             streamed = false;
         } else if (upload) {
-            GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage, h_in, bytes, hipMemcpyHostToDevice, p->rt_copy_stream));
+            upload_pieces();
         }
         gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
                               epoch, p->rt_groups, {}};

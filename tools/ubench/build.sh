@@ -14,4 +14,5 @@ $H -O3 --offload-arch=gfx950 tools/ubench/dep_chain.hip -o tools/ubench/bin/dep_
 
 $H -O2 --offload-arch=gfx950 tools/ubench/prearmed_copy.hip -o tools/ubench/bin/prearmed_copy
 $H -O3 --offload-arch=gfx950 -ffp-contract=off -I gpuaudiobench_amd/csrc -I include tools/ubench/far_transform.hip -o tools/ubench/bin/far_transform
+$H -O2 --offload-arch=gfx950 tools/ubench/torn_word.hip -o tools/ubench/bin/torn_word
 ls -la tools/ubench/bin
