@@ -2,7 +2,7 @@
 // A kernel watches a word of the destination while the engine copy lands and keeps the FIRST value it sees that is not the old one.
 // If the runtime cuts the copy into engine packets of 4 MiB - 1 BYTES, the word at bytes 4 194 300 - 4 194 303 straddles the first
 // boundary: its low three bytes arrive with one packet, its top byte with the next, and the watcher can see a mixture.
-//   tools/ubench/bin/torn_word [bytes] [copies]
+//   tools/ubench/bin/torn_word [bytes] [copies] [piece bytes: 0 = one copy] [source offset in bytes, a multiple of 4]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -24,10 +24,13 @@ __global__ void watch(const unsigned* dst, const unsigned* idx, int n, unsigned 
 int main(int argc, char** argv) {
     const size_t bytes = argc > 1 ? (size_t)atol(argv[1]) : (size_t(8) << 20);
     const int copies = argc > 2 ? atoi(argv[2]) : 2000;
+    const size_t piece = argc > 3 ? (size_t)atol(argv[3]) : 0;
+    const size_t src_off = argc > 4 ? (size_t)atol(argv[4]) : 0;
     const size_t words = bytes / 4;
-    unsigned* src = nullptr;
+    unsigned* src_base = nullptr;
     unsigned* dst = nullptr;
-    CK(hipHostMalloc(reinterpret_cast<void**>(&src), bytes, hipHostMallocDefault));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&src_base), bytes + 4096, hipHostMallocDefault));
+    unsigned* const src = src_base + src_off / 4;
     CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&dst), bytes, hipDeviceMallocFinegrained));
     const unsigned OLD = 0xffa5c3e1u;
     for (size_t i = 0; i < words; ++i) src[i] = 0x3e000000u + (unsigned)(i * 2654435761u >> 9);    // plain floats, top byte 0x3e/0x3f
@@ -49,7 +52,12 @@ int main(int argc, char** argv) {
         CK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(dst), (int)OLD, words));
         CK(hipDeviceSynchronize());
         watch<<<n, 64, 0, ks>>>(dst, d_idx, n, OLD, d_seen, 1 << 22);
-        CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+        if (!piece) {
+            CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+        } else {
+            for (size_t off = 0; off < bytes; off += piece)
+                CK(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, reinterpret_cast<const char*>(src) + off, bytes - off < piece ? bytes - off : piece, hipMemcpyHostToDevice, cs));
+        }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(seen.data(), d_seen, n * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {
@@ -57,7 +65,7 @@ int main(int argc, char** argv) {
             else if (seen[i] != src[use[i]]) { ++torn[i]; example[i] = seen[i]; }
         }
     }
-    printf("{\"bytes\": %zu, \"copies\": %d, \"old\": \"%08x\", \"words\": [", bytes, copies, OLD);
+    printf("{\"bytes\": %zu, \"copies\": %d, \"piece_bytes\": %zu, \"source_offset\": %zu, \"old\": \"%08x\", \"words\": [", bytes, copies, piece, src_off, OLD);
     for (int i = 0; i < n; ++i)
         printf("%s{\"word\": %u, \"first_byte\": %zu, \"torn\": %d, \"never_seen\": %d, \"new\": \"%08x\", \"example\": \"%08x\"}", i ? ", " : "", use[i], (size_t)use[i] * 4,
                torn[i], late[i], src[use[i]], example[i]);
