@@ -463,9 +463,13 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             // the sentinel (k_conv_accel.hip, kRtUploadPiece; profiles/r05_incident_torn_word.txt)
             {
                 const size_t bytes = sizeof(float) * (size_t)in_size, piece = (size_t(4) << 20) - 256;
-                for (size_t off = 0; off < bytes; off += piece)
-                    GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->stage) + off, reinterpret_cast<const char*>(h_in) + off,
-                                                 std::min(piece, bytes - off), hipMemcpyHostToDevice, p->copy_stream));
+                const size_t watched = sizeof(float) * (size_t)dep;     // the kernel only looks at the first `dep` words: what lies beyond goes up in one copy
+                for (size_t off = 0; off < bytes;) {
+                    const size_t n = off >= watched ? bytes - off : std::min(piece, bytes - off);
+                    GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->stage) + off, reinterpret_cast<const char*>(h_in) + off, n,
+                                                 hipMemcpyHostToDevice, p->copy_stream));
+                    off += n;
+                }
             }
             if (!streamed) GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
         }
