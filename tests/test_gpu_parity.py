@@ -436,7 +436,9 @@ def test_conv_accel_zero_copy_pinned_host_buffers(gab, orc):
         b.close()
 
 
-@pytest.mark.parametrize("T,L,n", [(64, 4096, 12), (1024, 4096, 12), (8, 1500, 10), (2052, 3000, 3), (8192, 4096, 2)])
+@pytest.mark.parametrize("T,L,n", [(64, 4096, 12), (1024, 4096, 12), (8, 1500, 10),
+                                   (2052, 3000, 40),     # 4.2 MB of input: ONE word straddles the runtime's 4 MiB - 1 byte engine-packet limit (r05_incident_torn_word.txt)
+                                   (8192, 4096, 4)])     # three such words
 def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, orc, T, L, n):
     """gab_conv_round_trip on the classic cut (engine upload consumed as it lands, far partition before the
     input, outputs drained per channel group): bit for bit what device-buffer launches of the same cut give,
