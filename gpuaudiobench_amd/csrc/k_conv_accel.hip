@@ -898,21 +898,25 @@ constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;   
 #endif
 struct ArriveAtBarrier { __device__ __forceinline__ void operator()(int) const { __syncthreads(); } };
 
-// ENGINE: the same launch fed through a doorbell (gab_conv_engine_*): it stays on the device and takes buffer nb from slot
-// nb % ring of an input ring when the doorbell word says it has been published, instead of n_buffers known at launch.
-//   doorbell   [pinned host memory] = buffers published so far, bit 31 = no more will come.  Only workgroup 0 reads it
-//              over the link — 256 workgroups asking the host every period cost 20-40 us per period, measured — and
-//              passes it on through a word in device memory (`relay`) that one lane of every workgroup (the first
-//              inverse wave's) asks for at the start of a period; the answer is needed at the period's end, so a
-//              producer that keeps a few buffers ahead never makes the engine wait; otherwise every wave of the
-//              workgroup parks at a barrier while that lane polls (bounded: then the engine stops with an error).
-//   period nb  runs when buffer nb + 1 is there too (its operands are requested one period ahead), or when the stop
-//              bit says buffer nb is the last; the output of buffer nb leaves one period later, as in a batch launch.
-//   progress   every inverse wave stores (write-through) how many buffers it has finished — one period late, when the
-//              rows' own stores have long drained, so nothing waits for it; one wave of workgroup 0 takes the minimum of
-//              all of them each period and writes it into `completed` (pinned host word).
+// ENGINE (gab_conv_engine_*, conv_split_engine_resident below): the batch launch's period code kept on the device; it takes
+// buffer nb from slot nb % ring of an input ring when the doorbell word says it has been published, instead of n_buffers known at
+// launch.
+//   doorbell   [pinned host memory] bits 0-29 buffers published so far, bit 31 STOP (no more will come), bit 30 FLUSH (finish what
+//              is published without waiting for more: round 5, ONE buffer in flight).  Only workgroup 0 reads it over the link —
+//              256 workgroups asking the host every period cost 20-40 us per period, measured — and passes it on through a word in
+//              device memory (`relay`) that one lane of every workgroup (the first inverse wave's) asks for at the start of a
+//              period; the answer is needed at the period's end, so a producer that keeps a few buffers ahead never makes the
+//              engine wait; otherwise every wave of the workgroup parks at a barrier while the first inverse wave polls (bounded:
+//              then the engine stops with an error).
+//   period nb  runs when buffer nb + 1 is there too (its operands are requested one period ahead), or — STOP or FLUSH — when
+//              buffer nb is the last one published: such a period requests nothing and ends its BURST; a drain period delivers
+//              the buffer, the workgroup idles in the gate and the next burst starts cold.  The output of buffer nb leaves one
+//              period after its own, as in a batch launch.
+//   progress   every inverse wave stores (write-through) how many buffers it has finished — pipelined: one period late, when the
+//              rows' own stores have long drained; at a burst's end: behind a wait for them.  The first inverse wave of workgroup 1
+//              takes the minimum of all of them (each period, and while it idles) and writes it into `completed` (pinned host word).
 // The history ring is written every period (the last eight buffers are not known in advance) and the far role takes
-// blocks k-7 .. k-2 from it, as round 3's batch kernel did; everything else is the batch launch's code: same bits.
+// blocks k-7 .. k-2 from it, as round 3's batch kernel did; everything else is the batch launch's period code: same bits.
 struct ConvEngine {
     const unsigned* doorbell;
     unsigned* relay;              // device: the doorbell as workgroup 0 last saw it (zero at launch)
