@@ -157,6 +157,9 @@ __global__ __launch_bounds__(kBlock) void datatransfer_kernel(const float* __res
 // landed, and an input that really holds it is released by the `landed` word the host sets once the copy's
 // event has completed.  Same expression per word as datatransfer_kernel: bit-identical output.
 constexpr unsigned kLinkSentinel = 0xffa5c3e1u;
+// landed = the word's top byte is no longer the sentinel's (k_conv_accel.hip, rt_pending: a word cut by an engine-packet boundary
+// shows the input's low bytes under the sentinel's high ones for a moment)
+__device__ __forceinline__ bool link_pending(unsigned w) { return (w >> 24) == (kLinkSentinel >> 24); }
 constexpr int kLinkPollLimit = 1 << 21;            // x ~0.5 us of s_sleep: about a second, then the launch gives up
 constexpr int kLinkChunk = 4 * kBlock;             // words per chunk: one float4 per thread
 struct LinkRoundTrip {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
             if (tid == 0) {
                 const unsigned* const last = rt.stage + min(chunk * kLinkChunk + kLinkChunk, dep) - 1;
                 int tries = 0, bad = gave_up ? 1 : 0;
-                while (!bad && link_peek(last) == kLinkSentinel) {
+                while (!bad && link_pending(link_peek(last))) {
                     if ((++tries & 63) == 0 && link_peek(rt.landed) == rt.epoch) break;     // the upload is in: it IS the sentinel
                     if (tries > kLinkPollLimit) { bad = 1; break; }
                     __builtin_amdgcn_s_sleep(20);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
             for (;;) {
                 bool all = true;
                 for (int k = 0; k < 4; ++k)
-                    if (k < n_in) { w[k] = link_peek(rt.stage + w0 + k); all = all && w[k] != kLinkSentinel; }
+                    if (k < n_in) { w[k] = link_peek(rt.stage + w0 + k); all = all && !link_pending(w[k]); }
                 if (all || gave_up) break;
                 // a word that is STILL the sentinel is a value only behind an acquire of `landed` (released by the host
                 // after the copy's completion event): one more look after the acquire is final

@@ -617,6 +617,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_split_host_io_kernel(
 //         signal (HIP: everything a kernel wrote is visible to the host once the launch's event has completed).
 // Same operations in the same order as conv_overlap_save_kernel<true, true>: bit-identical to device-buffer launches.
 constexpr unsigned kRtSentinel = 0xffa5c3e1u;       // a negative NaN with a payload
+// "Has this word landed?" looks at the word's TOP BYTE only: not the sentinel's 0xff.  An engine copy that is cut inside a word
+// (the runtime cuts at 4 MiB - 1 bytes; ours go out in word-aligned pieces, but the limit is the runtime's to change) leaves, for
+// a moment, the input's low bytes under the sentinel's high ones — still "not landed" by this test, where a whole-word compare took
+// it for a sample (profiles/r05_incident_torn_word.txt).  An input word whose own top byte is 0xff (a negative NaN, -inf, below
+// -1.7e38: no audio) waits for the upload's completion like the sentinel itself.
+__device__ __forceinline__ bool rt_pending(unsigned w) { return (w >> 24) == (kRtSentinel >> 24); }
 constexpr size_t kRtUploadPiece = (size_t(4) << 20) - 256;   // bytes per engine copy of an upload that a kernel consumes as it lands (below the runtime's 4 MiB - 1 packet limit, a multiple of 256)
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     const unsigned* const row = rt.stage + (size_t)ta * kB;                         // 2 x 512 words, contiguous
     if (tid == 0) {
         int tries = 0, bad = 0;
-        while (rt_peek(row + 2 * kB - 1) == kRtSentinel) {                          // the region's last word
+        while (rt_pending(rt_peek(row + 2 * kB - 1))) {                             // the region's last word
             // (a pinned word: looked at every 64th round only — 512 pollers reading it every round would be link traffic)
             if ((++tries & 63) == 0 && rt_peek(rt.landed) == rt.epoch) break;       // the whole upload is in: it IS the sentinel
             if (tries > kRtPollLimit) { bad = 1; break; }
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
             w[1] = rt_peek(row + tid + kThreads);
             w[2] = rt_peek(row + kB + tid);
             w[3] = rt_peek(row + kB + tid + kThreads);
-            if (gave_up || (w[0] != kRtSentinel && w[1] != kRtSentinel && w[2] != kRtSentinel && w[3] != kRtSentinel)) break;
+            if (gave_up || !(rt_pending(w[0]) || rt_pending(w[1]) || rt_pending(w[2]) || rt_pending(w[3]))) break;
             // A word that is STILL the sentinel counts as a sample only on this chain: the copy's completion signal (its
             // writes are visible at system scope before it: HSA) -> the host's hipEventQuery -> the host's release store
             // to `landed` -> THIS acquire load -> loads issued after it.  One more look behind the acquire is final.

@@ -223,7 +223,9 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * for the stream.  h_out must be pinned (hipHostMalloc) — the kernel writes it.  h_in: pinned for the overlap; pageable
  * memory is accepted and uploaded completely before the launch (the kernel consumes an upload as it lands only when every
  * word is written exactly once and in one piece, which engine copies from pinned memory do when no engine packet ends
- * inside a word: the upload goes out in pieces of 4 MiB - 256 bytes).  h_in is read from the moment of the
+ * inside a word: the upload goes out in pieces of 4 MiB - 256 bytes; and a staging word counts as landed when its top
+ * byte is no longer the sentinel's 0xff, so input words that are negative NaNs, -inf or below -1.7e38 wait for the
+ * upload's completion instead: slower, same bits).  h_in is read from the moment of the
  * call on the plan's own upload stream: it must be complete by then (the upload is NOT ordered behind work queued on
  * `stream`).  Blocking; one call at a time per plan.  The call returns when the LAUNCH HAS ENDED on `stream`
  * (the launch's own stop event has completed): from then on h_out is the host's and the staging buffer the next call's — the completion
