@@ -174,6 +174,127 @@ __global__ __launch_bounds__(kWG) void far_kernel(const cf* __restrict__ tw, con
     for (int r = 12; r < 16; ++r) out[(size_t)blockIdx.x * 1024 + ft + kFar * (r - 12)] = z[r];
 }
 
+// ---- twelve waves: two far groups (form B, 149 VGPRs: three waves per SIMD fit), each owning one pair and taking TWO periods per
+// transform, beside four near waves that run TWO wave-held transforms per iteration.  One iteration = two periods of the product kernel.
+// The partner exchange reuses the cross exchange's buffer behind one more barrier (two transforms must fit the LDS): five barriers.
+template <bool BESIDE>
+__global__ __launch_bounds__(768) void far12_kernel(const cf* __restrict__ tw, const cf* __restrict__ in, cf* __restrict__ out, int iters) {
+    __shared__ cf lds[2 * kHalf + 4 * kImg];
+    cf* const near_img = lds + 2 * kHalf;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int BARRIERS = 5;
+    if (w < 4) {
+        cf v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = mk(1e-3f * (float)(lane + 64 * r), 0.f);
+        fft::WaveFFT1024<false>::Lean tf;
+        fft::WaveFFT1024<false>::load_twiddles(tf, tw, lane);
+        for (int p = 0; p < iters; ++p) {
+            if (BESIDE) {
+                fft::WaveFFT1024<false>::run(v, near_img + w * kImg, tf, lane, Arrive());        // barriers 1, 2
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= (1.0f / 1024.0f);
+                fft::WaveFFT1024<false>::run(v, near_img + w * kImg, tf, lane, Arrive());        // barriers 3, 4 (the second period's near work)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= (1.0f / 1024.0f);
+                __syncthreads();                                                               // barrier 5
+            } else {
+                for (int i = 0; i < BARRIERS; ++i) __syncthreads();
+            }
+        }
+        if (v[0].x == 123.456f) out[0] = v[3];
+        return;
+    }
+    const int grp = (w - 4) >> 2;                            // far group 0 / 1: its own pair, its own LDS half
+    const int ft = (tid - 256) & 255, wv = (w - 4) & 3, j = lane;
+    cf* const E = lds + grp * kHalf;
+    cf z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = in[((size_t)blockIdx.x * 2 + grp) * kN % ((size_t)gridDim.x * kN) + ft + kFar * r];
+    using WF = fft::WaveFFT1024<false>;
+    using WFi = fft::WaveFFT1024<true>;
+    WF::Lean t;
+    WF::load_twiddles(t, tw, j);
+    const cf w1 = tw[ft], w2 = tw[(2 * ft) & (kN - 1)], w3 = tw[(3 * ft) & (kN - 1)];
+    cf P[16], M[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int k = 4 * (j + 64 * i) + wv; P[i] = specP(k); M[i] = specM(k); }
+    cf keep[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep[r] = z[r];
+    for (int p = 0; p < iters; ++p) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = keep[r];
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) fft::bfly4<false>(z[rp], z[rp + 4], z[rp + 8], z[rp + 12]);
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            z[rp + 4] = fft::cmul(z[rp + 4], w1);
+            z[rp + 8] = fft::cmul(z[rp + 8], w2);
+            z[rp + 12] = fft::cmul(z[rp + 12], w3);
+        }
+        z[1 + 4] = fft::tw16<false, 1>(z[1 + 4]); z[1 + 8] = fft::tw16<false, 2>(z[1 + 8]); z[1 + 12] = fft::tw16<false, 3>(z[1 + 12]);
+        z[2 + 4] = fft::tw16<false, 2>(z[2 + 4]); z[2 + 8] = fft::tw16<false, 4>(z[2 + 8]); z[2 + 12] = fft::tw16<false, 6>(z[2 + 12]);
+        z[3 + 4] = fft::tw16<false, 3>(z[3 + 4]); z[3 + 8] = fft::tw16<false, 6>(z[3 + 8]); z[3 + 12] = fft::tw16<false, 9>(z[3 + 12]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) E[q * kImg + ft + kFar * rp] = z[rp + 4 * q];
+        __syncthreads();                                                    // barrier 1
+        cf v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = E[wv * kImg + j + 64 * i];
+        WF::run(v, E + wv * kImg, t, j);
+        __syncthreads();                                                    // barrier 2: every wave's transform is through, E is free
+#pragma unroll
+        for (int i = 0; i < 16; ++i) E[wv * kImg + j + 64 * i] = v[i];       // partner exchange in the same buffer
+        __syncthreads();                                                    // barrier 3
+        const int qp = (4 - wv) & 3;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = j + 64 * i;
+            const int mp = wv == 0 ? ((1024 - m) & 1023) : 1023 - m;
+            const cf zp = E[qp * kImg + mp];
+            v[i] = fft::cfma_cj(zp, M[i], fft::cmul(v[i], P[i]));
+        }
+        __syncthreads();                                                    // barrier 4: partners read, the images may be written again
+        WFi::run(v, E + wv * kImg, t, j);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) E[wv * kImg + j + 64 * i] = v[i];
+        __syncthreads();                                                    // barrier 5
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const int n1 = ft + kFar * rp;
+            cf t0 = E[0 * kImg + n1], t1 = E[1 * kImg + n1], t2 = E[2 * kImg + n1], t3 = E[3 * kImg + n1];
+            t1 = fft::cmulc(t1, w1); t2 = fft::cmulc(t2, w2); t3 = fft::cmulc(t3, w3);
+            if (rp == 1) { t1 = fft::tw16<true, 1>(t1); t2 = fft::tw16<true, 2>(t2); t3 = fft::tw16<true, 3>(t3); }
+            if (rp == 2) { t1 = fft::tw16<true, 2>(t1); t2 = fft::tw16<true, 4>(t2); t3 = fft::tw16<true, 6>(t3); }
+            if (rp == 3) { t1 = fft::tw16<true, 3>(t1); t2 = fft::tw16<true, 6>(t2); t3 = fft::tw16<true, 9>(t3); }
+            z[12 + rp] = fft::addmi(fft::csub(t0, t2), fft::csub(t1, t3));
+        }
+#pragma unroll
+        for (int r = 12; r < 16; ++r) keep[r - 12] = keep[r - 12] + 1e-6f * z[r];
+    }
+#pragma unroll
+    for (int r = 12; r < 16; ++r) out[(size_t)blockIdx.x * 1024 + ft + kFar * (r - 12)] = z[r];
+}
+
+template <bool BESIDE>
+static double run12(const cf* tw, const cf* in, cf* out, int iters, int grid) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    far12_kernel<BESIDE><<<grid, 768>>>(tw, in, out, 50);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    far12_kernel<BESIDE><<<grid, 768>>>(tw, in, out, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3 / iters / 2.0;                       // per PERIOD: an iteration is two
+}
+
 template <int FORM, bool BESIDE>
 static double run(const cf* tw, const cf* in, cf* out, int periods, int grid) {
     hipEvent_t e0, e1;
@@ -228,5 +349,10 @@ int main(int argc, char** argv) {
     printf("{\"us_per_period\": {\"A_three_radix16_passes_6_barriers\": {\"alone\": [%.3f, %.3f], \"beside_near_waves\": [%.3f, %.3f]}, "
            "\"B_radix4_plus_wave_held_1024_4_barriers\": {\"alone\": [%.3f, %.3f], \"beside_near_waves\": [%.3f, %.3f]}}, \"periods\": %d, \"workgroups\": %d}\n",
            a_alone, a_alone2, a_beside, a_beside2, b_alone, b_alone2, b_beside, b_beside2, periods, grid);
+    const double c_alone = run12<false>(tw, in, outB, periods / 2, grid), c_beside = run12<true>(tw, in, outB, periods / 2, grid);
+    const double c_alone2 = run12<false>(tw, in, outB, periods / 2, grid), c_beside2 = run12<true>(tw, in, outB, periods / 2, grid);
+    printf("{\"us_per_period\": {\"C_twelve_waves_two_far_groups_of_form_B_two_periods_per_transform\": {\"alone\": [%.3f, %.3f], \"beside_near_waves\": [%.3f, %.3f]}}, "
+           "\"note\": \"one iteration = two periods (each far group turns one transform, the near waves two); 768 threads, three waves per SIMD\"}\n",
+           c_alone, c_alone2, c_beside, c_beside2);
     return 0;
 }
