@@ -641,22 +641,29 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     }
 
     # ---- the same call under DAW pacing: one buffer per 512/48000 s slot, device idle between
-    paced = []
-    daw = gab.harness.DawSim(buffer_seconds=float(B) / FS, mode="spin")
-    for i in range(105):
-        daw.wait()
-        t1 = time.perf_counter()
-        rplan.launch_round_trip(rt_args)
-        if i >= 5:
-            paced.append((time.perf_counter() - t1) * 1e6)
-    paced = np.array(paced)
-    waits, missed = daw.stats()
-    daw.close()
+    def paced_calls():
+        ts = []
+        daw = gab.harness.DawSim(buffer_seconds=float(B) / FS, mode="spin")
+        for i in range(105):
+            daw.wait()
+            t1 = time.perf_counter()
+            rplan.launch_round_trip(rt_args)
+            if i >= 5:
+                ts.append((time.perf_counter() - t1) * 1e6)
+        waits, missed = daw.stats()
+        daw.close()
+        ts = np.array(ts)
+        return {"p50_round_trip_us": float(np.percentile(ts, 50)), "p95_round_trip_us": float(np.percentile(ts, 95)),
+                "max_round_trip_us": float(ts.max()), "slots": int(waits), "missed_slots": int(missed)}
+
+    res["paced_10p667ms"] = paced_calls()
+    # the same slots with eight idle waves left on the device between calls (gab_conv_round_trip_keep_warm: opt-in)
+    rplan.round_trip_keep_warm(True)
+    rplan.launch_round_trip(rt_args)
+    res["paced_10p667ms"]["keep_warm"] = dict(paced_calls(), what="gab_conv_round_trip_keep_warm(plan, 1): every call ends by kicking a resident "
+                                              "launch of eight sleeping waves (one per XCD), which ends by itself 50 ms after the last call")
+    rplan.round_trip_keep_warm(False)
     rplan.close()
-    res["paced_10p667ms"] = {"p50_round_trip_us": float(np.percentile(paced, 50)),
-                             "p95_round_trip_us": float(np.percentile(paced, 95)),
-                             "max_round_trip_us": float(paced.max()),
-                             "slots": int(waits), "missed_slots": int(missed)}
     return res
 
 

@@ -9,7 +9,7 @@ CPU; if the shared object is missing the import fails.
 from . import _capi
 from ._capi import GabError, lib, check, CONV_STATELESS, CONV_STREAMING, CONV_STREAMING_HOST_IO, DWG_NAIVE, DWG_ACCEL
 from .ops import (noop, gain, gainstats, datatransfer, iir, conv1d, rndmem, modal, modal_bank, dwg,
-                  fft_r2c_1024, ConvPlan, FdtdPlan, LinkPlan, fdtd_default_params, device_count)
+                  fft_r2c_1024, ConvPlan, FdtdPlan, LinkPlan, KeepWarm, fdtd_default_params, device_count)
 
 from . import harness
 from .harness import Benchmark, benchmark_names
@@ -18,5 +18,5 @@ __all__ = [
     "harness", "Benchmark", "benchmark_names",
     "GabError", "lib", "check", "CONV_STATELESS", "CONV_STREAMING", "CONV_STREAMING_HOST_IO", "DWG_NAIVE", "DWG_ACCEL",
     "noop", "gain", "gainstats", "datatransfer", "iir", "conv1d", "rndmem", "modal", "modal_bank", "dwg",
-    "fft_r2c_1024", "ConvPlan", "FdtdPlan", "LinkPlan", "fdtd_default_params", "device_count",
+    "fft_r2c_1024", "ConvPlan", "FdtdPlan", "LinkPlan", "KeepWarm", "fdtd_default_params", "device_count",
 ]

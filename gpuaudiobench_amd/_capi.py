@@ -82,6 +82,10 @@ PROTOTYPES = {
     "gab_link_plan_create": (_I, [_I, C.POINTER(_P)]),
     "gab_link_plan_destroy": (None, [_P]),
     "gab_datatransfer_round_trip": (_I, [_P, _P, _P, _I, _I, _P]),
+    "gab_keep_warm_create": (_I, [C.POINTER(_P), _I, C.c_double]),
+    "gab_keep_warm_kick": (_I, [_P]),
+    "gab_keep_warm_running": (_I, [_P, C.POINTER(_I)]),
+    "gab_keep_warm_destroy": (_I, [_P]),
     "gab_iir": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_iir_sequential": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_conv1d": (_I, [_P, _P, _P, _I, _I, _I, _P]),
@@ -103,6 +107,7 @@ PROTOTYPES = {
     "gab_conv_process_batch": (_I, [_P, _P, _P, _I, _P]),
     "gab_conv_round_trip": (_I, [_P, _P, _P, _P]),
     "gab_conv_newest_block": (_I, [_P, _P, _P]),
+    "gab_conv_round_trip_keep_warm": (_I, [_P, _I]),
     "gab_conv_engine_rings": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P)]),
     "gab_conv_engine_start": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _P]),
     "gab_conv_engine_publish": (_I, [_P, _I]),
@@ -162,6 +167,7 @@ PROTOTYPES = {
     "gab_dawsim_stats": (_I, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "gab_dawsim_destroy": (_I, [_P]),
     "gab_bench_set_dawsim": (_I, [_P, _I, C.c_double, _I, C.c_double]),
+    "gab_bench_set_keep_warm": (_I, [_P, _I]),
     "gab_bench_dawsim_stats": (_I, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 

@@ -56,6 +56,8 @@ void printHelp() {
     printf("  --dawsim            Pace iterations to one buffer slot each (bufferSize / fs)\n");
     printf("  --dawsim-mode [m]   spin | sleep (default: spin)\n");
     printf("  --dawsim-jitter-us [us]  Uniform jitter on each slot (default: 0)\n");
+    printf("  --keepWarm          Leave eight idle waves on the device between iterations (with --dawsim: the device\n");
+    printf("                      does not go idle while the loop waits for the next slot)\n");
     printf("\nAvailable Benchmarks:\n=====================\n");
     printf("\nData Transfer:\n");
     printf("  datacopy0199     - 1%% input, 99%% output transfer\n");
@@ -89,6 +91,7 @@ void printHelp() {
 static bool g_dawsim = false;
 static BenchmarkUtils::DAWSimulationMode g_dawsim_mode = BenchmarkUtils::DAWSimulationMode::SPIN;
 static double g_dawsim_jitter_us = 0.0;
+static bool g_keep_warm = false;
 static bool g_validate_only = false;
 static int g_gpus = 0;              // 0: the reference's single-device path, no RCCL
 static bool g_validation_failed = false;
@@ -132,6 +135,7 @@ void runSelectedBenchmark(std::unique_ptr<GPUABenchmark> benchmark, const std::s
     try {
         printf("Setting up %s benchmark...\n", name.c_str());
         benchmark->setupBenchmark();
+        benchmark->setKeepWarm(g_keep_warm);
         if (g_dawsim) {
             BenchmarkUtils::DAWSimulator sim;
             sim.bufferDuration = (double)BUFSIZE / (double)FS;
@@ -305,6 +309,8 @@ int main(int argc, char** argv) {
             MODAL_REAL = strcmp(argv[++i], "bank") == 0 ? 1 : 0;
         } else if (strcmp(argv[i], "--dawsim") == 0) {
             g_dawsim = true;
+        } else if (strcmp(argv[i], "--keepWarm") == 0) {
+            g_keep_warm = true;
         } else if (strcmp(argv[i], "--dawsim-mode") == 0) {
             if (!need("--dawsim-mode")) return 1;
             const char* m = argv[++i];

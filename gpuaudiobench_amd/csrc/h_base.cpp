@@ -101,7 +101,12 @@ struct PacedLoop {
     bool paced;
     BenchmarkUtils::DAWSimulator* daw;
     BenchmarkUtils::DAWSimulationState clock;
-    void slot() { if (paced) daw->wait(clock); }
+    gab_keep_warm* warm = nullptr;              // setKeepWarm: there for the length of the run, kicked after every pass
+    void slot() {
+        if (warm) (void)gab_keep_warm_kick(warm);
+        if (paced) daw->wait(clock);
+    }
+    ~PacedLoop() { if (warm) (void)gab_keep_warm_destroy(warm); }
 };
 
 void announce(const char* fmt, int a, int b = 0) {
@@ -113,6 +118,8 @@ void announce(const char* fmt, int a, int b = 0) {
 GPUABenchmark::BenchmarkResult GPUABenchmark::runWithIteration(int iterations, int warmupIterations,
                                                               const std::function<void()>& body) {
     PacedLoop loop{this, daw_enabled_, &daw_simulator_, {}};
+    if (keep_warm_enabled_ && gab_keep_warm_create(&loop.warm, 8, 0.05) != GAB_OK)
+        throw std::runtime_error(std::string("keep-warm: ") + gab_last_error());
 
     // stage 1: untimed passes; an exception costs that pass only
     if (warmupIterations > 0) announce("Running %d warmup iterations...\n", warmupIterations);

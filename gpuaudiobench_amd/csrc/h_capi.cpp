@@ -309,6 +309,12 @@ int gab_bench_set_dawsim(gab_bench* b, int enable, double buffer_seconds, int mo
     });
 }
 
+int gab_bench_set_keep_warm(gab_bench* b, int enable) {
+    if (!b) return gab::bad_arg("gab_bench_set_keep_warm: null benchmark");
+    b->impl->setKeepWarm(enable != 0);
+    return GAB_OK;
+}
+
 int gab_bench_dawsim_stats(gab_bench* b, unsigned long long* waits, unsigned long long* missed_slots) {
     if (!b) return gab::bad_arg("gab_bench_dawsim_stats: null benchmark");
     if (waits) *waits = b->last.daw_waits;

@@ -318,6 +318,28 @@ __global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict_
     }
 }
 
+// ---- keep-warm: a resident launch that does nothing ------------------------------------------------------------
+// A device left alone for a DAW slot (512 / 48000 s) answers the next call later than one that has just been busy:
+// gab_conv_round_trip's p50 is 76-81 us paced against 67-70 back to back on the same box, and 67-68 paced with EIGHT idle
+// waves resident beside (one per XCD; one wave buys nothing, 64 and more cost: profiles/r05_paced_keep_warm.txt).  These waves sleep, look at a pinned word, sleep:
+// no LDS, no memory traffic but the look.  They end at the stop word, and by themselves `idle_ticks` of the 100 MHz
+// wall clock after the last kick — the exit every wave reaches.
+constexpr unsigned kKeepWarmStop = 0xffffffffu;
+
+__global__ __launch_bounds__(64) void keep_warm_kernel(const unsigned* kick, unsigned* gone, unsigned long long idle_ticks, int naps) {
+    unsigned last = link_peek(kick);
+    unsigned long long since = wall_clock64();
+    for (;;) {
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks: about 4 us each
+        const unsigned k = link_peek(kick);
+        if (k == kKeepWarmStop) break;
+        const unsigned long long now = wall_clock64();
+        if (k != last) { last = k; since = now; }
+        else if (now - since > idle_ticks) break;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 }  // namespace gab
 
@@ -552,6 +574,75 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         }
         return GAB_OK;
     });
+}
+
+// ---- keep-warm ---------------------------------------------------------------------------------------------------
+struct gab_keep_warm {
+    hipStream_t stream = nullptr;      // its own, highest priority: a resident launch holds its hardware queue, and streams
+                                       // of the default priority never share one with it (profiles/r05_incident_engine_queue_sharing.txt)
+    unsigned* words = nullptr;         // pinned host: [0] the kick count / stop word, [16] set by the launch as it ends
+    unsigned count = 0;
+    int workgroups = 1;
+    int naps = 16;                     // a look every ~64 us: the looks cross the link the round trip uses (64 waves looking every 4 us cost it 7 us)
+    double idle_seconds = 0.25;
+    bool launched = false;
+    ~gab_keep_warm() {
+        if (words && launched) __atomic_store_n(&words[0], gab::kKeepWarmStop, __ATOMIC_RELEASE);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (words) (void)hipHostFree(words);
+    }
+};
+
+int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_seconds) {
+    return gab::guarded([&]() -> int {
+        if (!out) return gab::bad_arg("gab_keep_warm_create: null argument");
+        if (workgroups < 1 || workgroups > 256) return gab::bad_arg("gab_keep_warm_create: 1..256 workgroups (one wave each)");
+        if (!(idle_seconds > 0.0 && idle_seconds <= 10.0)) return gab::bad_arg("gab_keep_warm_create: idle_seconds must be in (0, 10]");
+        auto k = std::make_unique<gab_keep_warm>();
+        k->workgroups = workgroups;
+        k->idle_seconds = idle_seconds;
+#ifdef GAB_ABLATE
+        if (getenv("GAB_KEEP_WARM_NAPS")) k->naps = std::max(1, atoi(getenv("GAB_KEEP_WARM_NAPS")));   // diagnostic builds: how often the waves look
+#endif
+        int lo = 0, hi = 0;
+        GAB_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        GAB_HIP_CHECK(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, hi));
+        GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&k->words), 32 * sizeof(unsigned), hipHostMallocDefault));
+        for (int i = 0; i < 32; ++i) k->words[i] = 0;
+        *out = k.release();
+        return GAB_OK;
+    });
+}
+
+int gab_keep_warm_kick(gab_keep_warm* k) {
+    return gab::guarded([&]() -> int {
+        if (!k) return gab::bad_arg("gab_keep_warm_kick: null argument");
+        if (++k->count == gab::kKeepWarmStop) k->count = 1;
+        if (k->launched && __atomic_load_n(&k->words[16], __ATOMIC_ACQUIRE) == 0) {
+            __atomic_store_n(&k->words[0], k->count, __ATOMIC_RELEASE);          // the launch is there: push its end out
+            return GAB_OK;
+        }
+        if (k->launched) GAB_HIP_CHECK(hipStreamSynchronize(k->stream));          // it said it was ending: let it
+        k->words[16] = 0;
+        __atomic_store_n(&k->words[0], k->count, __ATOMIC_RELEASE);
+        gab::keep_warm_kernel<<<dim3(k->workgroups), dim3(64), 0, k->stream>>>(k->words, k->words + 16,
+                                                                               (unsigned long long)(k->idle_seconds * 1e8), k->naps);
+        int rc = gab::launch_status("keep_warm_kernel");
+        if (rc) return rc;
+        k->launched = true;
+        return GAB_OK;
+    });
+}
+
+int gab_keep_warm_running(gab_keep_warm* k, int* running) {
+    if (!k || !running) return gab::bad_arg("gab_keep_warm_running: null argument");
+    *running = k->launched && __atomic_load_n(&k->words[16], __ATOMIC_ACQUIRE) == 0;
+    return GAB_OK;
+}
+
+int gab_keep_warm_destroy(gab_keep_warm* k) {
+    delete k;
+    return GAB_OK;
 }
 
 int gab_modal(const float* d_params, float* d_out, int n_modes, int bufsize, int out_tracks,

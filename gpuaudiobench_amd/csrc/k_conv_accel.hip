@@ -2150,6 +2150,8 @@ struct gab_conv_plan {
     hipStream_t rt_copy_stream = nullptr;
     hipEvent_t rt_copy_ev = nullptr;
     hipEvent_t rt_done_ev = nullptr;      // the launch's own completion (what gab_conv_round_trip returns on)
+    gab_keep_warm* warm = nullptr;        // gab_conv_round_trip_keep_warm: kicked at the end of every round trip while warm_on
+    bool warm_on = false;
     unsigned rt_epoch = 0;
     int rt_groups = 0;
     unsigned rt_bound[gab::kRtMaxGroups + 1] = {};
@@ -2272,6 +2274,7 @@ int gab_conv_destroy(gab_conv_plan* p) {
         (void)hipStreamSynchronize(p->eng_stream);                   // (a null handle is the default stream)
         p->eng_running = false;
     }
+    if (p->warm) { (void)gab_keep_warm_destroy(p->warm); p->warm = nullptr; }   // (a resident launch: before the device-wide wait)
     (void)hipDeviceSynchronize();
     if (p->pmA) (void)hipFree(p->pmA);
     if (p->pmB) (void)hipFree(p->pmB);
@@ -2647,6 +2650,18 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         }
         if (*error != 0) return after_a_failed_wait("a workgroup waited about a second for its input and gave up");
         if (*done != epoch) return after_a_failed_wait("the launch ended without draining every channel group");
+        if (p->warm_on) (void)gab_keep_warm_kick(p->warm);       // the result is out: keep the device from going idle until the next slot
+        return GAB_OK;
+    });
+}
+
+int gab_conv_round_trip_keep_warm(gab_conv_plan* p, int on) {
+    return gab::guarded([&]() -> int {
+        if (!p) return gab::bad_arg("gab_conv_round_trip_keep_warm: null plan");
+        if (on && !p->warm) {
+            if (int rc = gab_keep_warm_create(&p->warm, 8, 0.05)) return rc;
+        }
+        p->warm_on = on != 0;
         return GAB_OK;
     });
 }

@@ -145,6 +145,10 @@ class Benchmark:
         check(lib.gab_bench_set_dawsim(self._h, 1 if enable else 0, buffer_seconds,
                                        DawSim.MODES[mode], jitter_us * 1e-6))
 
+    def set_keep_warm(self, enable=True):
+        """Leave eight idle waves on the device for the length of run(), kicked after every iteration (gab_keep_warm)."""
+        check(lib.gab_bench_set_keep_warm(self._h, 1 if enable else 0))
+
     def dawsim_stats(self):
         w, m = C.c_ulonglong(0), C.c_ulonglong(0)
         check(lib.gab_bench_dawsim_stats(self._h, C.byref(w), C.byref(m)))

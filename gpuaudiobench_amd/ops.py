@@ -80,6 +80,35 @@ def datatransfer(x, out_size):
     return out
 
 
+class KeepWarm:
+    """gab_keep_warm: a small resident launch that keeps the device from going idle between real-time slots
+    (kick() once per slot; it ends by itself idle_seconds after the last kick)."""
+
+    def __init__(self, workgroups=8, idle_seconds=0.25):
+        h = C.c_void_p()
+        check(lib.gab_keep_warm_create(C.byref(h), int(workgroups), float(idle_seconds)))
+        self._h = h
+
+    def kick(self):
+        check(lib.gab_keep_warm_kick(self._h))
+
+    def running(self):
+        v = C.c_int(0)
+        check(lib.gab_keep_warm_running(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def close(self):
+        if self._h:
+            lib.gab_keep_warm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LinkPlan:
     """gab_link_plan: the staging buffer, words and upload stream of datatransfer with both link directions
     busy at once (gab_datatransfer_round_trip)."""
@@ -226,6 +255,10 @@ class ConvPlan:
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         check(lib.gab_conv_round_trip(self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr()), st))
         return h_out
+
+    def round_trip_keep_warm(self, on=True):
+        """Every later round trip of this plan ends with a keep-warm kick (gab_conv_round_trip_keep_warm)."""
+        check(lib.gab_conv_round_trip_keep_warm(self._h, 1 if on else 0))
 
     def newest_block(self):
         """The block the plan consumed last ([tracks*512], the input's layout), from its history ring

@@ -141,6 +141,11 @@ public:
     void clearDawSimulator() { daw_enabled_ = false; }
     bool hasDawSimulator() const { return daw_enabled_; }
     const BenchmarkUtils::DAWSimulator& dawSimulator() const { return daw_simulator_; }
+    // Keep-warm (additive; gab_keep_warm in gab_c_api.h): for the length of a run, a resident launch of eight sleeping
+    // waves is kicked after every iteration, so the device does not go idle while the loop waits for the next slot
+    // (at C3 a paced round trip answers ~9 us sooner: profiles/r05_paced_keep_warm.txt).  Off by default.
+    void setKeepWarm(bool on) { keep_warm_enabled_ = on; }
+    bool keepWarm() const { return keep_warm_enabled_; }
 
     // ---- identity and shape (bench_base.cuh:116-119) --------------------------------------------
     const std::string& getName() const { return benchmark_name_; }
@@ -182,4 +187,5 @@ protected:
     hipStream_t stream_ = nullptr;             // all of this benchmark's device work
     BenchmarkUtils::DAWSimulator daw_simulator_;
     bool daw_enabled_ = false;
+    bool keep_warm_enabled_ = false;
 };

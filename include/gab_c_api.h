@@ -80,6 +80,28 @@ void gab_link_plan_destroy(gab_link_plan* plan);
 int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h_out, int in_size, int out_size,
                                 gab_stream_t stream);
 
+/* ---- keep-warm (additive; no counterpart in the reference, whose iterations run back to back) ---------------------
+ * A device left idle for a DAW slot (512 / 48000 s = 10.667 ms) answers the next call later than one that has just been
+ * busy: at C3 gab_conv_round_trip's p50 is 76-81 us one call per slot against 67-70 us back to back on the same box — and
+ * 67-68 us per slot with EIGHT idle waves resident beside (profiles/r05_paced_keep_warm.txt: one wave buys nothing — the
+ * workgroups of a launch go round the eight XCDs, eight wake them all; 64 waves and more cost, their looks cross the link
+ * the round trip is using).  A gab_keep_warm is that launch: `workgroups` single-wave workgroups that sleep and look at a
+ * pinned word every ~64 us (no LDS, no memory traffic but the look), on a highest-priority stream of their own.
+ * gab_keep_warm_kick starts the launch if none is there and pushes its end out otherwise: the launch ends by itself
+ * `idle_seconds` after the last kick (and at destroy, at once).  Kick once per slot.
+ * Opt-in, because it costs what resident waves cost (power, one wave slot on `workgroups` compute units) and because,
+ * like the engine below, the launch is THERE: hipDeviceSynchronize, hipFree and hipHostFree — which wait for every launch
+ * on the device — return only once it has ended (up to idle_seconds after the last kick), and work queued on another
+ * stream that the runtime maps to the same hardware queue stands behind it for as long (streams of the default priority
+ * never share a queue with it: profiles/r05_incident_engine_queue_sharing.txt).  Keep idle_seconds short: a few slots.
+ * gab_conv_round_trip_keep_warm(plan, 1) makes every gab_conv_round_trip of that plan end with a kick (0: no more kicks,
+ * the launch ends idle_seconds later; the plan owns the object: 8 workgroups, 0.05 s).                                 */
+typedef struct gab_keep_warm gab_keep_warm;
+int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_seconds);
+int gab_keep_warm_kick(gab_keep_warm* warm);
+int gab_keep_warm_running(gab_keep_warm* warm, int* running);
+int gab_keep_warm_destroy(gab_keep_warm* warm);
+
 /* IIRFilterKernel (cuda/bench_iir.cu:10-44): DF-II biquad per track,
  * coeffs = {b0,b1,b2,a1,a2} (HOST pointer, 5 floats), d_state = T x {z1,z2}
  * read and written back.
@@ -235,6 +257,8 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * the staging buffer has been re-armed, the next call works.  A launch that could not be made leaves the plan as it
  * was (history, epoch, staging buffer).                                                                      */
 int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
+/* Every later gab_conv_round_trip of this plan ends with a gab_keep_warm_kick (see keep-warm above); on = 0 stops kicking. */
+int gab_conv_round_trip_keep_warm(gab_conv_plan* plan, int on);
 /* The block the plan consumed LAST, as its kernels keep it (the newest slot of the history ring of a 512-sample
  * plan), written to d_out in the input's layout [tracks][512].  An inspection call (additive): after
  * gab_conv_round_trip it must equal that call's h_in word for word — the check of the upload hand-off that tests
@@ -497,6 +521,9 @@ int gab_dawsim_stats(const gab_dawsim* s, unsigned long long* waits, unsigned lo
 int gab_dawsim_destroy(gab_dawsim* s);
 /* pace every warm-up and timed iteration of gab_bench_run (enable = 0 turns it off) */
 int gab_bench_set_dawsim(gab_bench* b, int enable, double buffer_seconds, int mode, double jitter_seconds);
+/* leave a gab_keep_warm launch (8 workgroups, 0.05 s) on the device for the length of every gab_bench_run and kick it after
+ * every iteration: with pacing on, the device does not go idle while the loop waits for the next slot (enable = 0: off) */
+int gab_bench_set_keep_warm(gab_bench* b, int enable);
 /* pacing counters of the last gab_bench_run */
 int gab_bench_dawsim_stats(gab_bench* b, unsigned long long* waits, unsigned long long* missed_slots);
 

@@ -497,6 +497,52 @@ def test_conv_accel_round_trip_overlapped_link_same_bits_as_device_buffers(gab, 
     b.close()
 
 
+def test_keep_warm_launch_comes_and_goes_and_changes_no_bits(gab, orc):
+    """gab_keep_warm: a kick starts the resident launch, later kicks push its end out, it ends by itself idle_seconds after
+    the last one and a kick brings it back; a plan whose round trips kick one (gab_conv_round_trip_keep_warm) gives the
+    same bits as one that does not, also while a keep-warm of the widest shape sits on the device; destroying a plan or
+    a keep-warm with the launch still there returns at once (the stop word, not the idle limit)."""
+    import time, torch
+    w = gab.KeepWarm(workgroups=256, idle_seconds=0.05)
+    assert not w.running()
+    w.kick()
+    assert w.running()
+    for _ in range(10):                                  # 0.1 s of kicks: twice the idle limit
+        time.sleep(0.01)
+        w.kick()
+    assert w.running()
+    time.sleep(0.3)
+    assert not w.running()
+    w.kick()
+    assert w.running()
+    T, B, L = 64, 512, 4096
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="classic")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    b.round_trip_keep_warm(True)
+    h_in, h_out = torch.empty(T * B).pin_memory(), torch.empty(T * B).pin_memory()
+    for i in range(12):
+        x = orc.noise(T * B, seed=300 + i)
+        h_in.copy_(torch.from_numpy(x))
+        ya = host(a.process(dev(x), mode=gab.CONV_STREAMING))
+        yb = b.round_trip(h_in, h_out).numpy()
+        assert not where_bits_differ(ya, yb, T), "buffer %d: %s" % (i, where_bits_differ(ya, yb, T))
+        w.kick()
+    b.close()                                            # its launch is still there: the stop word ends it
+    w.close()
+    w = gab.KeepWarm(workgroups=8, idle_seconds=2.0)
+    w.kick()
+    t0 = time.perf_counter()
+    w.close()                                            # the stop word, not the idle limit
+    assert time.perf_counter() - t0 < 0.5
+    a.close()
+    with pytest.raises(gab.GabError):
+        gab.KeepWarm(workgroups=0)
+    with pytest.raises(gab.GabError):
+        gab.KeepWarm(workgroups=8, idle_seconds=0.0)
+
+
 def test_conv_accel_round_trip_input_that_holds_the_sentinel(gab, orc):
     """A buffer that really contains the staging sentinel (a NaN no audio carries) is released by the upload's
     completion instead of by the words changing: slower, same bits as the device-buffer launch (NaNs and all)."""

@@ -42,6 +42,33 @@ def test_every_registered_benchmark_validates(gab, name):
     b.close()
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_every_registered_benchmark_paced_with_keep_warm(gab, name):
+    """--dawsim --keepWarm: eight idle waves stay on the device for the length of the run (gab_keep_warm, kicked after
+    every iteration).  Nothing an iteration does may wait for them: every benchmark still validates, and a run lasts
+    its slots, not its slots plus an idle limit per iteration."""
+    import time
+    cfg = dict(n_tracks=128, buffer_size=512)
+    if name == "FDTD3D":
+        cfg.update(n_tracks=16, buffer_size=64)
+    b = gab.Benchmark(name, **cfg)
+    b.setup()
+    slot = 0.004
+    b.set_dawsim(buffer_seconds=slot, mode="spin")
+    b.set_keep_warm(True)
+    b.run(iterations=2, warmup=1)                       # (first-use costs of this benchmark's kernels)
+    t0 = time.perf_counter()
+    r = b.run(iterations=6, warmup=2)
+    elapsed = time.perf_counter() - t0
+    v, text = b.validate()
+    assert v.status == 0, (name, text, v.max_error)
+    assert r.median_ms < 40.0, (name, r.median_ms)      # an iteration that waited for the idle limit (50 ms) would show here
+    waits, missed = b.dawsim_stats()
+    assert waits == 8
+    assert elapsed < 8 * max(slot, r.max_ms * 1e-3) + 0.5, (name, elapsed)
+    b.close()
+
+
 @pytest.mark.parametrize("mode", ["stream", "stateless"])
 def test_conv_accel_c3_through_the_harness(gab, mode):
     b = gab.Benchmark("Conv1D_accel", n_tracks=1024, buffer_size=512, ir_length=4096,
