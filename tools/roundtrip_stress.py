@@ -2,7 +2,7 @@
 pageable inputs mixed.  Every compared call is set up so that ONE mismatch classifies itself (tests/rt_diag.py): h_out is
 refilled with NaN, the block the kernel consumed is read back and compared with h_in, the previous call's input and
 output are kept.
-    python tools/roundtrip_stress.py [channels] [buffers]"""
+    python tools/roundtrip_stress.py [channels] [buffers]        (KEEP_WARM=1: with gab_conv_round_trip_keep_warm on)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +17,8 @@ B, L = 512, 4096
 ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
 a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="classic")
 a.set_ir(ir); b.set_ir(ir)
+if os.environ.get("KEEP_WARM"):
+    b.round_trip_keep_warm(True)
 h_in, h_out = torch.empty(T * B).pin_memory(), torch.empty(T * B).pin_memory()
 bad = 0
 prev_out = prev_in = None
