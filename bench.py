@@ -661,7 +661,7 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     rplan.round_trip_keep_warm(True)
     rplan.launch_round_trip(rt_args)
     res["paced_10p667ms"]["keep_warm"] = dict(paced_calls(), what="gab_conv_round_trip_keep_warm(plan, 1): every call ends by kicking a resident "
-                                              "launch of eight sleeping waves (one per XCD), which ends by itself 50 ms after the last call")
+                                              "launch of eight sleeping waves (one per XCD), which ends by itself about 0.1 s (eight buffer periods) after the last call")
     rplan.round_trip_keep_warm(False)
     rplan.close()
     return res

@@ -118,7 +118,8 @@ void announce(const char* fmt, int a, int b = 0) {
 GPUABenchmark::BenchmarkResult GPUABenchmark::runWithIteration(int iterations, int warmupIterations,
                                                               const std::function<void()>& body) {
     PacedLoop loop{this, daw_enabled_, &daw_simulator_, {}};
-    if (keep_warm_enabled_ && gab_keep_warm_create(&loop.warm, 8, 0.05) != GAB_OK)
+    // (the launch must outlive the wait for the next slot: four slots, at least 50 ms)
+    if (keep_warm_enabled_ && gab_keep_warm_create(&loop.warm, 8, std::min(10.0, std::max(0.05, daw_enabled_ ? 4.0 * daw_simulator_.bufferDuration : 0.05))) != GAB_OK)
         throw std::runtime_error(std::string("keep-warm: ") + gab_last_error());
 
     // stage 1: untimed passes; an exception costs that pass only

@@ -2659,7 +2659,8 @@ int gab_conv_round_trip_keep_warm(gab_conv_plan* p, int on) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_conv_round_trip_keep_warm: null plan");
         if (on && !p->warm) {
-            if (int rc = gab_keep_warm_create(&p->warm, 8, 0.05)) return rc;
+            // the launch must outlive the gap between two calls: several buffer periods even at a low sampling rate
+            if (int rc = gab_keep_warm_create(&p->warm, 8, std::max(0.05, 8.0 * p->bufsize / 44100.0))) return rc;
         }
         p->warm_on = on != 0;
         return GAB_OK;

@@ -95,7 +95,8 @@ int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h
  * stream that the runtime maps to the same hardware queue stands behind it for as long (streams of the default priority
  * never share a queue with it: profiles/r05_incident_engine_queue_sharing.txt).  Keep idle_seconds short: a few slots.
  * gab_conv_round_trip_keep_warm(plan, 1) makes every gab_conv_round_trip of that plan end with a kick (0: no more kicks,
- * the launch ends idle_seconds later; the plan owns the object: 8 workgroups, 0.05 s).                                 */
+ * the launch ends idle_seconds later; the plan owns the object: 8 workgroups, idle limit = eight buffer periods at
+ * 44.1 kHz, at least 0.05 s).                                 */
 typedef struct gab_keep_warm gab_keep_warm;
 int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_seconds);
 int gab_keep_warm_kick(gab_keep_warm* warm);
@@ -521,7 +522,7 @@ int gab_dawsim_stats(const gab_dawsim* s, unsigned long long* waits, unsigned lo
 int gab_dawsim_destroy(gab_dawsim* s);
 /* pace every warm-up and timed iteration of gab_bench_run (enable = 0 turns it off) */
 int gab_bench_set_dawsim(gab_bench* b, int enable, double buffer_seconds, int mode, double jitter_seconds);
-/* leave a gab_keep_warm launch (8 workgroups, 0.05 s) on the device for the length of every gab_bench_run and kick it after
+/* leave a gab_keep_warm launch (8 workgroups; idle limit four pacing slots, at least 0.05 s) on the device for the length of every gab_bench_run and kick it after
  * every iteration: with pacing on, the device does not go idle while the loop waits for the next slot (enable = 0: off) */
 int gab_bench_set_keep_warm(gab_bench* b, int enable);
 /* pacing counters of the last gab_bench_run */
