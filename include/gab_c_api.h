@@ -96,7 +96,8 @@ int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h
  * never share a queue with it: profiles/r05_incident_engine_queue_sharing.txt).  Keep idle_seconds short: a few slots.
  * gab_conv_round_trip_keep_warm(plan, 1) makes every gab_conv_round_trip of that plan end with a kick (0: no more kicks,
  * the launch ends idle_seconds later; the plan owns the object: 8 workgroups, idle limit = eight buffer periods at
- * 44.1 kHz, at least 0.05 s).                                 */
+ * 44.1 kHz, at least 0.05 s).
+ * One thread at a time per object (like a plan).  gab_keep_warm_running: is the launch on the device right now?                */
 typedef struct gab_keep_warm gab_keep_warm;
 int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_seconds);
 int gab_keep_warm_kick(gab_keep_warm* warm);
