@@ -116,6 +116,20 @@ def test_driver_runs_gain_and_writes_reference_outputs(tmp_path):
     assert rows[0].startswith("benchmark,fs,bufferSize,nTracks,nRuns,") and rows[1].startswith("gain,48000,512,64,7,")
 
 
+def test_driver_dawsim_keep_warm_round_trip():
+    """gpubench --dawsim --keepWarm on the round-trip iteration: validates, keeps its slots, and exits at once (the resident
+    launch is stopped at the end of the run, not waited out)."""
+    import time
+    t0 = time.perf_counter()
+    r = run_driver("--benchmark", "Conv1D_accel", "--nTracks", "256", "--irLength", "4096", "--convMode", "roundtrip",
+                   "--nRuns", "30", "--cpu-threads", "0", "--dawsim", "--keepWarm")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DAW simulation: 33 slots, " in r.stdout, r.stdout[-1500:]
+    assert "Validation passed for Conv1D_accel" in r.stdout
+    assert time.perf_counter() - t0 < 60
+    assert "--keepWarm" in run_driver("--help").stdout
+
+
 def test_driver_json_and_unknown_name():
     r = run_driver("--benchmark", "IIRFilter", "--nRuns", "5", "--json")
     assert r.returncode == 0
