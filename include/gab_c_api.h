@@ -232,8 +232,10 @@ int gab_conv_process(gab_conv_plan* plan, const float* d_in, float* d_out,
  * gab_conv_process; for callers whose input is resident ahead of time (offline rendering, and
  * bench.py's throughput figure): no kernel boundary between buffers.  On the split cut a 512-thread
  * workgroup owns a duo of channel pairs for the whole launch, near role on four waves, far role on
- * the other four (conv_split_batch_kernel).  Additive: the reference processes one buffer per
- * iteration.                                                                     */
+ * the other four (conv_split_batch_kernel).  A call of more than 256 buffers goes out as launches of at most 256 on
+ * `stream` (a launch boundary keeps the workgroups in step: over many hundred buffers they drift apart and the output
+ * lines leave the L2s in pieces — 5.63 against 5.10 us per buffer at 2048; profiles/r05_batch_buffers_per_launch.txt).
+ * Additive: the reference processes one buffer per iteration.                                                      */
 int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
                            int n_buffers, gab_stream_t stream);
 /* One buffer from pinned host memory to pinned host memory, returning when h_out holds the result — the

@@ -866,6 +866,7 @@ def test_conv_accel_engine_whose_producer_goes_away_ends_by_itself_and_says_so(g
 @pytest.mark.parametrize("T,B,L,n", [(64, 512, 4096, 11), (1024, 512, 4096, 5), (8, 512, 1500, 9), (5, 512, 2000, 3),
                                       (4, 512, 1100, 37), (2048, 512, 4096, 3), (12, 512, 4096, 1), (36, 512, 3000, 2),
                                       (8192, 512, 4096, 2),      # C5's channel count: 2048 workgroups, eight rounds of the device
+                                      (8, 512, 4096, 300),       # more buffers than ONE launch takes (256): the call cuts them into launches
 
                                       (16, 512, 512, 4), (3, 256, 700, 5)])
 def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
