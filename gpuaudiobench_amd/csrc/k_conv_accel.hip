@@ -2885,40 +2885,39 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
         if (p->eng_running) return gab::bad_arg("gab_conv_process_batch: the plan's engine is running and owns its history (gab_conv_engine_stop first)");
         if (n_buffers <= 0) return gab::bad_arg("gab_conv_process_batch: n_buffers must be > 0");
         hipStream_t s = gab::as_stream(stream);
-        if (p->fused && p->split) {
-            // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches
-            p->order_after_reset(s);
-            gab::ConvSplit sp{p->pmA2, p->pmF, p->carry GAB_SPLIT_DEBUG_ARG};
+        if (p->fused && (p->split || p->tail)) {
             // At most kBatchChunk buffers per launch.  Nothing holds the workgroups of a launch together, and the eight duos
             // whose 16-byte pieces make up one 128-byte output line must store within a period or two of each other — the
             // spectra streaming through an XCD's L2 turn it over every two periods — or the line leaves the L2 in pieces.
             // Over many hundred periods they drift apart: at 2048 buffers per launch the L2s send 2.75 x the write requests
-            // and 1.9 x the bytes per buffer, and a buffer takes 5.63 us instead of 5.17 (profiles/r05_batch_buffers_per_launch.txt).
-            // A launch boundary puts them back in step for the price of one cold start per chunk (0.03 us per buffer).
+            // and 1.9 x the bytes per buffer, and a buffer takes 5.63 us instead of 5.17 (profiles/r05_batch_buffers_per_launch.txt;
+            // the classic cut's launch: 10.5 instead of 9.3).  A launch boundary puts them back in step for the price of one
+            // cold start per chunk (0.03 us per buffer).
             size_t chunk_max = gab::kBatchChunk;
 #ifdef GAB_ABLATE
             if (getenv("GAB_BATCH_CHUNK")) chunk_max = std::max(1, atoi(getenv("GAB_BATCH_CHUNK")));   // diagnostic builds: to measure the above
 #endif
+            if (p->split) p->order_after_reset(s);
+            gab::ConvSplit sp{p->pmA2, p->pmF, p->carry GAB_SPLIT_DEBUG_ARG};
             const size_t step = (size_t)p->tracks * p->bufsize;
             for (int done = 0; done < n_buffers;) {
                 const int n = (int)std::min<size_t>(chunk_max, (size_t)(n_buffers - done));
-                gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
-                    d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
-                int rc = gab::launch_status("conv_split_batch_kernel");
+                int rc;
+                if (p->split) {
+                    // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches
+                    gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
+                        d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
+                    rc = gab::launch_status("conv_split_batch_kernel");
+                } else {
+                    gab::conv_batch_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
+                        d_in + done * step, d_out + done * step, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head, n);
+                    rc = gab::launch_status("conv_batch_kernel");
+                }
                 if (rc) return rc;
                 p->head = (p->head + n) & (gab::kSlots - 1);
                 p->fresh = false;
                 done += n;
             }
-            return GAB_OK;
-        }
-        if (p->fused && p->tail) {
-            gab::conv_batch_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
-                d_in, d_out, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head, n_buffers);
-            int rc = gab::launch_status("conv_batch_kernel");
-            if (rc) return rc;
-            p->head = (p->head + n_buffers) & (gab::kSlots - 1);
-            p->fresh = false;
             return GAB_OK;
         }
         // other shapes: one buffer at a time

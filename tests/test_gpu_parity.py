@@ -897,6 +897,21 @@ def test_conv_accel_batch_equals_one_launch_per_buffer(gab, orc, T, B, L, n):
     b.close()
 
 
+def test_conv_accel_batch_call_longer_than_one_launch_on_the_classic_cut(gab, orc):
+    """gab_conv_process_batch cuts a call into launches of at most 256 buffers (a launch's workgroups drift apart over many
+    hundred periods): on the classic cut too the 300 buffers of one call are the bits of 300 launches."""
+    T, B, L, n = 8, 512, 4096, 300
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="classic"), gab.ConvPlan(T, B, L, scheme="classic")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    x = np.concatenate([orc.noise(T * B, seed=500 + i) for i in range(n)])
+    seq = np.concatenate([host(a.process(dev(x[i * T * B:(i + 1) * T * B]), mode=gab.CONV_STREAMING)) for i in range(n)])
+    assert np.array_equal(bits(seq), bits(host(b.process_batch(dev(x), n))))
+    a.close()
+    b.close()
+
+
 def test_conv_accel_split_and_classic_streams_agree(gab, orc):
     """The split cut (far partition every other buffer, one buffer ahead, on its own workgroups)
     and the classic cut are the same convolution: 30 buffers agree to rounding, against each other

@@ -17,7 +17,7 @@ for T in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]:
     n = int(os.environ.get("NBUF", n))                           # NBUF=4032: one launch as long as the engine's bench leg
     alg = 4 * T * (2 * B + 2 * L)
     ir = torch.from_numpy(gab.harness.conv_accel_ir(L, T)).cuda()
-    a, b = gab.ConvPlan(T, B, L), gab.ConvPlan(T, B, L)
+    a, b = gab.ConvPlan(T, B, L, scheme=os.environ.get("SCHEME")), gab.ConvPlan(T, B, L, scheme=os.environ.get("SCHEME"))   # SCHEME=classic: the other cut
     a.set_ir(ir); b.set_ir(ir)
     del ir
     x = torch.empty(n * T * B, device="cuda").uniform_(-1, 1)
