@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3
 python3 - $OUT $T <<'PY' | tee $OUT/means.txt
 import csv, glob, sys, os
 out, T = sys.argv[1], int(sys.argv[2])
-n = 64 if T <= 2048 else (16 if T <= 16384 else 8)
+n = int(os.environ.get("NBUF", 64 if T <= 16384 else 32))      # as tools/batch_conv.py chooses
 alg = 4 * T * (2 * 512 + 2 * 4096) * n
 vals = {}
 for f in sorted(glob.glob(os.path.join(out, "pmc_*_counter_collection.csv"))):
