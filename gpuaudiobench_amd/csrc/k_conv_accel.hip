@@ -2729,6 +2729,9 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
                                      std::to_string(p->tracks) + " channels — shard the channels (one engine per device) or use gab_conv_process_batch").c_str());
         }
         if (int rc = gab_conv_engine_rings(p, ring_buffers, d_in_ring, d_out_ring)) return rc;
+        // The engine needs every compute unit WHOLE (two waves of 256 registers on each SIMD): with the plan's keep-warm waves on eight of
+        // them it could not become resident.  It keeps the device awake itself.
+        if (p->warm) { (void)gab_keep_warm_destroy(p->warm); p->warm = nullptr; p->warm_on = false; }
         hipStream_t caller = gab::as_stream(stream);
         // the launch goes on the plan's own stream, behind whatever the caller's stream holds now
         GAB_HIP_CHECK(hipEventRecord(p->eng_ev, caller));

@@ -97,6 +97,9 @@ int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h
  * gab_conv_round_trip_keep_warm(plan, 1) makes every gab_conv_round_trip of that plan end with a kick (0: no more kicks,
  * the launch ends idle_seconds later; the plan owns the object: 8 workgroups, idle limit = eight buffer periods at
  * 44.1 kHz, at least 0.05 s).
+ * NOT beside a resident engine: gab_conv_engine_start needs every compute unit whole (its workgroup fills the register files), so
+ * with keep-warm waves on eight of them it cannot become resident until they have ended — stop kicking (or destroy the object)
+ * first; the engine keeps the device awake itself, and gab_conv_engine_start drops the plan's own keep-warm.
  * One thread at a time per object (like a plan).  gab_keep_warm_running: is the launch on the device right now?                */
 typedef struct gab_keep_warm gab_keep_warm;
 int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_seconds);
