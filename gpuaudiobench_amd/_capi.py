@@ -85,6 +85,7 @@ PROTOTYPES = {
     "gab_keep_warm_create": (_I, [C.POINTER(_P), _I, C.c_double]),
     "gab_keep_warm_kick": (_I, [_P]),
     "gab_keep_warm_running": (_I, [_P, C.POINTER(_I)]),
+    "gab_keep_warm_placement": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),
     "gab_keep_warm_destroy": (_I, [_P]),
     "gab_iir": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
     "gab_iir_sequential": (_I, [_P, _P, C.POINTER(_F), _P, _I, _I, _P]),
@@ -108,6 +109,7 @@ PROTOTYPES = {
     "gab_conv_round_trip": (_I, [_P, _P, _P, _P]),
     "gab_conv_newest_block": (_I, [_P, _P, _P]),
     "gab_conv_round_trip_keep_warm": (_I, [_P, _I]),
+    "gab_conv_round_trip_keep_warm_placement": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),
     "gab_conv_engine_rings": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P)]),
     "gab_conv_engine_start": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _P]),
     "gab_conv_engine_publish": (_I, [_P, _I]),
@@ -118,6 +120,8 @@ PROTOTYPES = {
     "gab_conv_engine_feed": (_I, [_P, _I, _I]),
     "gab_conv_engine_feed_one_in_flight": (_I, [_P, _I, _P]),
     "gab_conv_engine_stop": (_I, [_P]),
+    "gab_conv_engine_round_trip": (_I, [_P, _P, _P]),
+    "gab_conv_engine_set_idle_limit": (_I, [_P, C.c_double]),
     "gab_conv_state_bytes": (_I, [_P, C.POINTER(_Z), C.POINTER(_Z)]),
     "gab_fdtd_default_params": (_I, [_I, _I, _I, C.POINTER(FdtdParams)]),
     "gab_fdtd_create": (_I, [C.POINTER(_P), C.POINTER(FdtdParams)]),

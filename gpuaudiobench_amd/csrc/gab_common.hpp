@@ -59,6 +59,17 @@ inline int launch_status(const char* kernel) {
 
 inline hipStream_t as_stream(gab_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Launches that STAY on a device (gab_runtime.cpp): the keep-warm launch and the doorbell-fed engine.  They exclude each
+// other — the engine's workgroup fills a compute unit's register files, so eight keep-warm waves keep eight of its
+// workgroups out until they end (profiles/r05_paced_keep_warm.txt: first buffer 484 ms) — and the library makes every one
+// of them, so it knows: whoever would start the second is refused at the call.
+enum ResidentKind { kResidentKeepWarm = 0, kResidentEngine = 1 };
+using ResidentProbe = bool (*)(const void* owner);       // is the owner's launch on the device right now?
+void resident_add(const void* owner, int device, ResidentKind kind, ResidentProbe running);
+void resident_remove(const void* owner);
+// how many launches of `kind` are running on `device`, not counting `except` (may be null)
+int resident_running(int device, ResidentKind kind, const void* except);
+
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kNumXCD = 8;          // MI355X: 8 XCDs, blocks are dealt round-robin over them
 

@@ -2,6 +2,8 @@
 #include "gab_common.hpp"
 
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace gab {
 namespace {
@@ -22,6 +24,29 @@ int refuse_unsupported_runtime_mode(const char* who) {
         return GAB_ERR_UNSUPPORTED;
     }
     return GAB_OK;
+}
+
+namespace {
+struct Resident { const void* owner; int device; ResidentKind kind; ResidentProbe running; };
+std::mutex g_resident_mu;
+std::vector<Resident>& residents() { static std::vector<Resident> v; return v; }
+}
+void resident_add(const void* owner, int device, ResidentKind kind, ResidentProbe running) {
+    std::lock_guard<std::mutex> lock(g_resident_mu);
+    residents().push_back({owner, device, kind, running});
+}
+void resident_remove(const void* owner) {
+    std::lock_guard<std::mutex> lock(g_resident_mu);
+    auto& v = residents();
+    for (size_t i = 0; i < v.size();)
+        if (v[i].owner == owner) v.erase(v.begin() + (long)i); else ++i;
+}
+int resident_running(int device, ResidentKind kind, const void* except) {
+    std::lock_guard<std::mutex> lock(g_resident_mu);
+    int n = 0;
+    for (const Resident& r : residents())
+        if (r.device == device && r.kind == kind && r.owner != except && r.running(r.owner)) ++n;
+    return n;
 }
 }  // namespace gab
 

@@ -325,19 +325,36 @@ __global__ __launch_bounds__(kBlock) void rndmem_kernel(const float* __restrict_
 // no LDS, no memory traffic but the look.  They end at the stop word, and by themselves `idle_ticks` of the 100 MHz
 // wall clock after the last kick — the exit every wave reaches.
 constexpr unsigned kKeepWarmStop = 0xffffffffu;
+constexpr int kKeepWarmWords = 32;          // [0] the kick count / stop word, [16] set by the launch as it ends; then two words per workgroup
 
-__global__ __launch_bounds__(64) void keep_warm_kernel(const unsigned* kick, unsigned* gone, unsigned long long idle_ticks, int naps) {
+// Workgroup 0 ALONE decides that the launch has been idle long enough: it says so in `gone`, and the other waves leave when
+// they see that word or the stop word.  (Round 5 let every wave run its own timer: a kick arriving right at expiry could
+// keep some waves and lose others — a launch that looked alive with fewer waves than asked for, or one that looked gone
+// with stragglers the next kick then waited idle_seconds for.)  The others' own timer is only the exit they reach if
+// workgroup 0 never says anything: twice the limit.
+// `where`: [2 b] HW_ID, [2 b + 1] XCC_ID | 1 << 31 of workgroup b's wave, written once at its start — which XCD, shader
+// engine and compute unit the wave landed on (profiles/r05_paced_keep_warm.txt has a half-run in which explicitly made
+// objects bought nothing; the one fact that would classify it is whether the eight waves sat on eight XCDs).
+__global__ __launch_bounds__(64) void keep_warm_kernel(const unsigned* kick, unsigned* gone, unsigned* where,
+                                                       unsigned long long idle_ticks, int naps) {
+    if (threadIdx.x == 0) {
+        where[2 * blockIdx.x] = __builtin_amdgcn_s_getreg(63492);                    // HW_ID
+        __hip_atomic_store(&where[2 * blockIdx.x + 1], __builtin_amdgcn_s_getreg(63508) | 0x80000000u,   // XCC_ID, behind the first word
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const bool decides = blockIdx.x == 0;
     unsigned last = link_peek(kick);
     unsigned long long since = wall_clock64();
     for (;;) {
         for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks: about 4 us each
         const unsigned k = link_peek(kick);
         if (k == kKeepWarmStop) break;
+        if (!decides && link_peek(gone) != 0) break;
         const unsigned long long now = wall_clock64();
         if (k != last) { last = k; since = now; }
-        else if (now - since > idle_ticks) break;
+        else if (now - since > (decides ? idle_ticks : 2 * idle_ticks)) break;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (decides && threadIdx.x == 0) __hip_atomic_store(gone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -580,13 +597,17 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
 struct gab_keep_warm {
     hipStream_t stream = nullptr;      // its own, highest priority: a resident launch holds its hardware queue, and streams
                                        // of the default priority never share one with it (profiles/r05_incident_engine_queue_sharing.txt)
-    unsigned* words = nullptr;         // pinned host: [0] the kick count / stop word, [16] set by the launch as it ends
+    unsigned* words = nullptr;         // pinned host: [0] the kick count / stop word, [16] set by the launch as it ends,
+                                       // [32 + 2 b], [33 + 2 b] where workgroup b's wave landed (HW_ID, XCC_ID | 1 << 31)
     unsigned count = 0;
     int workgroups = 1;
+    int device = 0;
     int naps = 16;                     // a look every ~64 us: the looks cross the link the round trip uses (64 waves looking every 4 us cost it 7 us)
     double idle_seconds = 0.25;
     bool launched = false;
+    bool running() const { return launched && __atomic_load_n(&words[16], __ATOMIC_ACQUIRE) == 0; }
     ~gab_keep_warm() {
+        gab::resident_remove(this);
         if (words && launched) __atomic_store_n(&words[0], gab::kKeepWarmStop, __ATOMIC_RELEASE);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         if (words) (void)hipHostFree(words);
@@ -605,10 +626,14 @@ int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_second
         if (getenv("GAB_KEEP_WARM_NAPS")) k->naps = std::max(1, atoi(getenv("GAB_KEEP_WARM_NAPS")));   // diagnostic builds: how often the waves look
 #endif
         int lo = 0, hi = 0;
+        GAB_HIP_CHECK(hipGetDevice(&k->device));
         GAB_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         GAB_HIP_CHECK(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, hi));
-        GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&k->words), 32 * sizeof(unsigned), hipHostMallocDefault));
-        for (int i = 0; i < 32; ++i) k->words[i] = 0;
+        const int words = gab::kKeepWarmWords + 2 * workgroups;
+        GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&k->words), words * sizeof(unsigned), hipHostMallocDefault));
+        for (int i = 0; i < words; ++i) k->words[i] = 0;
+        gab::resident_add(k.get(), k->device, gab::kResidentKeepWarm,
+                          [](const void* o) { return static_cast<const gab_keep_warm*>(o)->running(); });
         *out = k.release();
         return GAB_OK;
     });
@@ -618,14 +643,25 @@ int gab_keep_warm_kick(gab_keep_warm* k) {
     return gab::guarded([&]() -> int {
         if (!k) return gab::bad_arg("gab_keep_warm_kick: null argument");
         if (++k->count == gab::kKeepWarmStop) k->count = 1;
-        if (k->launched && __atomic_load_n(&k->words[16], __ATOMIC_ACQUIRE) == 0) {
+        if (k->running()) {
             __atomic_store_n(&k->words[0], k->count, __ATOMIC_RELEASE);          // the launch is there: push its end out
             return GAB_OK;
         }
-        if (k->launched) GAB_HIP_CHECK(hipStreamSynchronize(k->stream));          // it said it was ending: let it
-        k->words[16] = 0;
+        // A doorbell-fed engine on this device holds every compute unit's registers until its stop: the launch could only
+        // queue up behind it (and would then keep the NEXT engine start out).  The engine keeps the device awake itself.
+        if (gab::resident_running(k->device, gab::kResidentEngine, nullptr) > 0)
+            return gab::bad_arg("gab_keep_warm_kick: a gab_conv_engine launch is resident on this device and fills its compute units; "
+                                "the keep-warm launch cannot start beside it (and is not needed: the engine keeps the device awake) — "
+                                "gab_conv_engine_stop first");
+        if (k->launched) {
+            // workgroup 0 said the launch was ending: the stop word makes every straggler leave at its next look
+            __atomic_store_n(&k->words[0], gab::kKeepWarmStop, __ATOMIC_RELEASE);
+            GAB_HIP_CHECK(hipStreamSynchronize(k->stream));
+        }
+        for (int i = 0; i < 2 * k->workgroups; ++i) k->words[gab::kKeepWarmWords + i] = 0;
         __atomic_store_n(&k->words[0], k->count, __ATOMIC_RELEASE);
-        gab::keep_warm_kernel<<<dim3(k->workgroups), dim3(64), 0, k->stream>>>(k->words, k->words + 16,
+        __atomic_store_n(&k->words[16], 0u, __ATOMIC_RELEASE);
+        gab::keep_warm_kernel<<<dim3(k->workgroups), dim3(64), 0, k->stream>>>(k->words, k->words + 16, k->words + gab::kKeepWarmWords,
                                                                                (unsigned long long)(k->idle_seconds * 1e8), k->naps);
         int rc = gab::launch_status("keep_warm_kernel");
         if (rc) return rc;
@@ -636,7 +672,24 @@ int gab_keep_warm_kick(gab_keep_warm* k) {
 
 int gab_keep_warm_running(gab_keep_warm* k, int* running) {
     if (!k || !running) return gab::bad_arg("gab_keep_warm_running: null argument");
-    *running = k->launched && __atomic_load_n(&k->words[16], __ATOMIC_ACQUIRE) == 0;
+    *running = k->running() ? 1 : 0;
+    return GAB_OK;
+}
+
+int gab_keep_warm_placement(gab_keep_warm* k, unsigned* hw_id, unsigned* xcc_id, int capacity, int* started) {
+    if (!k || !started) return gab::bad_arg("gab_keep_warm_placement: null argument");
+    if (capacity < 0 || (capacity > 0 && (!hw_id || !xcc_id))) return gab::bad_arg("gab_keep_warm_placement: capacity without arrays");
+    int n = 0;
+    for (int b = 0; b < k->workgroups; ++b) {
+        const unsigned x = __atomic_load_n(&k->words[gab::kKeepWarmWords + 2 * b + 1], __ATOMIC_ACQUIRE);
+        if (!(x >> 31)) continue;                                                // this wave has not started (yet)
+        if (n < capacity) {
+            hw_id[n] = __atomic_load_n(&k->words[gab::kKeepWarmWords + 2 * b], __ATOMIC_RELAXED);
+            xcc_id[n] = x & 0x7fffffffu;
+        }
+        ++n;
+    }
+    *started = n;
     return GAB_OK;
 }
 

@@ -181,7 +181,12 @@ __device__ unsigned long long g_split_stamps[2 * 8 * 8192];
 // the transforms are bound by LDS write bandwidth and VALU throughput, not by the
 // per-thread instruction chain, and radix-8 needs a third exchange.)
 // One buffer of one channel pair; the body of the kernels below.
-template <bool STREAM, bool TAIL>
+// LOOPED: the caller walks several buffers through this body in one launch (conv_batch_kernel).  Everything that depends
+// on the thread index alone (both partitions' twiddle powers, 84 registers; addresses) is loop-invariant there and the
+// compiler kept it across the whole body — 256 registers and 24 bytes of scratch per lane.  With an opaque copy of the
+// thread index per buffer the body is the single-buffer launch's (197 registers, the powers re-formed per buffer as
+// there) and nothing spills.
+template <bool STREAM, bool TAIL, bool LOOPED = false>
 __device__ __forceinline__ void conv_one_buffer(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const float4* __restrict__ pmB,
@@ -189,7 +194,9 @@ __device__ __forceinline__ void conv_one_buffer(
     cf* const lds0 = lds;
     cf* const lds1 = lds + kLdsHalf;
 
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    if constexpr (LOOPED) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int q = xcd_contiguous(blockIdx.x, gridDim.x);
     const int ta = 2 * q, tb = 2 * q + 1;
     const bool hasb = tb < T;
@@ -859,8 +866,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
     __shared__ cf lds[2 * kLdsHalf];
     const size_t step = (size_t)T * kB;
     for (int nb = 0; nb < n_buffers; ++nb)
-        conv_one_buffer<true, true>(in + nb * step, out + nb * step, hist, pmA, pmB, tw, T,
-                                       (head + nb) & (kSlots - 1), lds);
+        conv_one_buffer<true, true, true>(in + nb * step, out + nb * step, hist, pmA, pmB, tw, T,
+                                             (head + nb) & (kSlots - 1), lds);
 }
 
 // ---- split cut, n buffers per launch: a duo of channel pairs in ONE resident workgroup -------------------
@@ -932,8 +939,11 @@ struct ConvEngine {
     unsigned* error;              // pinned host
     int ring;                     // buffers in the input and output rings (>= 3)
     int poll_every_period;        // 1; diagnostic builds may turn it off (the word is then read only when the engine stalls)
+    unsigned* started;            // device: workgroups that have begun (zero at launch)
+    unsigned* resident;           // pinned host: [0] = 1 once the first workgroup runs, [1] = workgroups once the last one does
+    unsigned long long idle_ticks;   // of the 100 MHz wall clock: a stalled workgroup gives up after that long without the doorbell moving
 };
-constexpr int kEnginePollLimit = 3 << 20;      // x ~0.7-2 us a look: two to six seconds without the word moving
+constexpr double kEngineIdleSeconds = 4.0;     // the default of gab_conv_engine_set_idle_limit
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // experiments only (GAB_EXTRA_FLAGS=-DGAB_ENGV=bits, a build of its own): 1 no progress words / aggregator, 2 plain output
@@ -1304,7 +1314,15 @@ __device__ __forceinline__ void conv_split_engine_resident(
         }
         return __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    if (tid == 0) s_door[2] = 0;
+    if (tid == 0) {
+        s_door[2] = 0;
+        // has the launch become resident?  The first and the last workgroup to begin say so in host words: a wait that
+        // runs out can then tell "never started" (something ahead of it on its hardware queue) and "some workgroups are
+        // kept out" (waves of another launch hold registers or LDS on their compute units) from a silent producer
+        const unsigned before = __hip_atomic_fetch_add(eng.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == 0) __hip_atomic_store(&eng.resident[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (before + 1 == gridDim.x) __hip_atomic_store(&eng.resident[1], gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1359,6 +1377,7 @@ __device__ __forceinline__ void conv_split_engine_resident(
                 if (w == 2) {                                         // the first inverse wave polls (lane 0 asks; workgroup 0's also aggregates)
                     unsigned v = 0;
                     int tries = 0;
+                    const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
                     for (;;) {
                         u4 pa, pb;
                         if (aggregator && !GAB_EABL(1)) aggregate_request(pa, pb);
@@ -1368,7 +1387,7 @@ __device__ __forceinline__ void conv_split_engine_resident(
                         if (aggregator && !GAB_EABL(1)) aggregate_report(pa, pb);
                         const int p2 = (int)(v & 0x3fffffffu);
                         if (p2 >= nb + 2 || (v >> 31) || (((v >> 30) & 1u) && p2 >= nb + 1)) break;
-                        if (++tries > kEnginePollLimit) {             // the producer is gone: stop here, say so
+                        if ((++tries & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t_poll > eng.idle_ticks) {   // the producer is gone: stop here, say so
                             if (lane == 0) {
                                 __hip_atomic_store(eng.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 s_door[2] = 1;
@@ -2161,8 +2180,11 @@ struct gab_conv_plan {
     float* eng_in = nullptr;            // fine-grained device memory: [ring][T*B], the producer writes it while the launch runs
     float* eng_out = nullptr;           // [ring][B*T]
     unsigned* eng_done = nullptr;       // device: buffers finished per inverse wave [2 x workgroups]
-    unsigned* eng_words = nullptr;      // pinned host: [0] doorbell, [16] completed, [32] error
+    unsigned* eng_words = nullptr;      // pinned host: [0] doorbell, [16] completed, [32] error, [48] first workgroup runs, [49] all of them do
     int eng_ring = 0;
+    double eng_idle_seconds = gab::kEngineIdleSeconds;   // gab_conv_engine_set_idle_limit
+    hipStream_t eng_copy_stream = nullptr;   // gab_conv_engine_round_trip: the two link legs (engine copies)
+    hipEvent_t eng_copy_ev = nullptr;
     bool eng_running = false;
     unsigned eng_published = 0;
     unsigned eng_seen_completed = 0;
@@ -2263,6 +2285,8 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
             gab_conv_destroy(p);
             throw;
         }
+        gab::resident_add(p, p->device, gab::kResidentEngine,
+                          [](const void* o) { return static_cast<const gab_conv_plan*>(o)->eng_running; });
         *out = p;
         return GAB_OK;
     });
@@ -2270,6 +2294,7 @@ int gab_conv_create(gab_conv_plan** out, int tracks, int bufsize, int ir_len) {
 
 int gab_conv_destroy(gab_conv_plan* p) {
     if (!p) return GAB_OK;
+    gab::resident_remove(p);
     if (p->eng_running) {                                            // never leave a resident launch behind: ring the stop rung FIRST
         if (p->eng_words) __atomic_store_n(&p->eng_words[0], p->eng_published | 0x80000000u, __ATOMIC_RELEASE);
         (void)hipStreamSynchronize(p->eng_stream);                   // (a null handle is the default stream)
@@ -2299,6 +2324,8 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->rt_copy_ev) (void)hipEventDestroy(p->rt_copy_ev);
     if (p->eng_ev) (void)hipEventDestroy(p->eng_ev);
     if (p->eng_own_stream) (void)hipStreamDestroy(p->eng_own_stream);
+    if (p->eng_copy_ev) (void)hipEventDestroy(p->eng_copy_ev);
+    if (p->eng_copy_stream) (void)hipStreamDestroy(p->eng_copy_stream);
     if (p->rt_done_ev) (void)hipEventDestroy(p->rt_done_ev);
     if (p->rt_copy_stream) (void)hipStreamDestroy(p->rt_copy_stream);
     delete p;
@@ -2668,6 +2695,12 @@ int gab_conv_round_trip_keep_warm(gab_conv_plan* p, int on) {
     });
 }
 
+int gab_conv_round_trip_keep_warm_placement(gab_conv_plan* p, unsigned* hw_id, unsigned* xcc_id, int capacity, int* started) {
+    if (!p || !started) return gab::bad_arg("gab_conv_round_trip_keep_warm_placement: null argument");
+    if (!p->warm) { *started = 0; return GAB_OK; }               // no keep-warm launch has been made for this plan
+    return gab_keep_warm_placement(p->warm, hw_id, xcc_id, capacity, started);
+}
+
 int gab_conv_newest_block(gab_conv_plan* p, float* d_out, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p || !d_out) return gab::bad_arg("gab_conv_newest_block: null argument");
@@ -2729,15 +2762,22 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
                                      std::to_string(p->tracks) + " channels — shard the channels (one engine per device) or use gab_conv_process_batch").c_str());
         }
         if (int rc = gab_conv_engine_rings(p, ring_buffers, d_in_ring, d_out_ring)) return rc;
-        // The engine needs every compute unit WHOLE (two waves of 256 registers on each SIMD): with the plan's keep-warm waves on eight of
-        // them it could not become resident.  It keeps the device awake itself.
+        // The engine needs every compute unit WHOLE (two waves of 256 registers on each SIMD): with keep-warm waves on eight of
+        // them it cannot become resident until they have ended (first buffer 484 ms: profiles/r05_paced_keep_warm.txt).  It
+        // keeps the device awake itself.  The plan's own keep-warm goes; anybody else's is the caller's to end — said here,
+        // at the failing call, instead of a first buffer that answers half a second late.
         if (p->warm) { (void)gab_keep_warm_destroy(p->warm); p->warm = nullptr; p->warm_on = false; }
+        if (const int others = gab::resident_running(p->device, gab::kResidentKeepWarm, nullptr))
+            return gab::bad_arg(("gab_conv_engine_start: " + std::to_string(others) + " gab_keep_warm launch" + (others > 1 ? "es are" : " is") +
+                                 " resident on this device (a KeepWarm object, or a harness run with keep-warm on); their waves keep the engine's "
+                                 "workgroups off their compute units until they end — gab_keep_warm_destroy (or stop kicking and wait out "
+                                 "idle_seconds) before the engine is started").c_str());
         hipStream_t caller = gab::as_stream(stream);
         // the launch goes on the plan's own stream, behind whatever the caller's stream holds now
         GAB_HIP_CHECK(hipEventRecord(p->eng_ev, caller));
         GAB_HIP_CHECK(hipStreamWaitEvent(p->eng_own_stream, p->eng_ev, 0));
         hipStream_t s = p->eng_own_stream;
-        const size_t prog_words = 2 * (size_t)(p->tracks / 4) + 32;        // + the relay word on a line of its own
+        const size_t prog_words = 2 * (size_t)(p->tracks / 4) + 64;        // + the started count and the relay word, a line of their own each
         if (!p->eng_done) GAB_HIP_CHECK(hipMalloc(&p->eng_done, prog_words * sizeof(unsigned)));
         if (!p->eng_words) {
             GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->eng_words), 64 * sizeof(unsigned), hipHostMallocDefault));
@@ -2751,7 +2791,8 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
         if (getenv("GAB_ENGINE_NOPOLL")) poll = 0;      // diagnostic builds: the doorbell is read only when the engine stalls
 
 #endif
-        gab::ConvEngine eng{p->eng_words, p->eng_done + prog_words - 1, p->eng_done, p->eng_words + 16, p->eng_words + 32, ring_buffers, poll};
+        gab::ConvEngine eng{p->eng_words, p->eng_done + prog_words - 1, p->eng_done, p->eng_words + 16, p->eng_words + 32, ring_buffers, poll,
+                            p->eng_done + prog_words - 33, p->eng_words + 48, (unsigned long long)(p->eng_idle_seconds * 1e8)};
         gab::conv_split_engine_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
             p->eng_in, p->eng_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, eng);
         int rc = gab::launch_status("conv_split_engine_kernel");
@@ -2804,8 +2845,23 @@ int gab_conv_engine_wait(gab_conv_plan* p, int count, double timeout_seconds) {
                 return GAB_ERR_RUNTIME;
             }
             if ((++spins & 0xfffu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds) {
+                // was the launch ever there?  (the first / the last workgroup to begin say so: [48], [49])
+                const unsigned first = __atomic_load_n(&p->eng_words[48], __ATOMIC_ACQUIRE), all = __atomic_load_n(&p->eng_words[49], __ATOMIC_ACQUIRE);
+                int on_device = 0;
+                (void)gab_conv_engine_running(p, &on_device);
+                std::string where;
+                if (!first)
+                    where = on_device ? "; the launch has NOT STARTED: no workgroup has run yet — something stands ahead of it on its hardware queue (a kernel or "
+                                        "device-to-device copy on another highest-priority stream), or another resident launch fills the device"
+                                      : "; the launch is no longer on the device and never ran a workgroup";
+                else if (!all)
+                    where = "; the launch is only PARTLY resident: some of its " + std::to_string(p->tracks / 4) + " workgroups have not begun — waves of another "
+                            "launch hold registers or LDS on their compute units (every workgroup must be resident at once)";
+                else
+                    where = on_device ? "; every workgroup of the launch is resident and waiting for the doorbell"
+                                      : "; the launch was resident and has ended";
                 gab::set_last_error("gab_conv_engine_wait: " + std::to_string(done) + " of " + std::to_string(count) +
-                                    " buffers reported within the time limit (without the flush rung a buffer is reported once five later ones are published)");
+                                    " buffers reported within the time limit (without the flush rung a buffer is reported once five later ones are published)" + where);
                 return GAB_ERR_RUNTIME;
             }
         }
@@ -2870,13 +2926,77 @@ int gab_conv_engine_stop(gab_conv_plan* p) {
         __atomic_store_n(&p->eng_words[0], p->eng_published | 0x80000000u, __ATOMIC_RELEASE);
         GAB_HIP_CHECK(hipStreamSynchronize(p->eng_stream));
         p->eng_running = false;
-        p->eng_seen_completed = p->eng_published;            // the launch has ended: everything published is finished
-        p->head = (p->head + (int)(p->eng_published & 7u)) & (gab::kSlots - 1);
         if (p->eng_words[32]) {
-            gab::set_last_error("gab_conv_engine_stop: the engine had given up waiting for the doorbell (about two seconds without a buffer or the stop)");
+            // The engine had given up (the doorbell silent for the idle limit): it ended its burst with what it had taken, and
+            // buffers published behind that (a pipelined burst without the flush rung leaves the last one waiting for its
+            // successor) were never consumed.  History ring, carry ring and head go on from what WAS consumed: every inverse
+            // wave's own count, read now that the launch is over — not from what was published.
+            const size_t waves = 2 * (size_t)(p->tracks / 4);
+            std::vector<unsigned> prog(waves);
+            GAB_HIP_CHECK(hipMemcpy(prog.data(), p->eng_done, waves * sizeof(unsigned), hipMemcpyDeviceToHost));
+            unsigned consumed = p->eng_published;
+            for (unsigned v : prog) consumed = std::min(consumed, v);
+            p->eng_seen_completed = consumed;
+            p->head = (p->head + (int)(consumed & 7u)) & (gab::kSlots - 1);
+            gab::set_last_error("gab_conv_engine_stop: the engine had given up waiting for the doorbell (" + std::to_string(p->eng_idle_seconds) +
+                                " s without a buffer or the stop: gab_conv_engine_set_idle_limit); it consumed " + std::to_string(consumed) + " of the " +
+                                std::to_string(p->eng_published) + " buffers published — the plan's history continues behind buffer " + std::to_string(consumed) +
+                                ", later ones were dropped and must be published again after the next start");
             return GAB_ERR_RUNTIME;
         }
+        p->eng_seen_completed = p->eng_published;            // the launch has ended: everything published is finished
+        p->head = (p->head + (int)(p->eng_published & 7u)) & (gab::kSlots - 1);
         return GAB_OK;
+    });
+}
+
+int gab_conv_engine_set_idle_limit(gab_conv_plan* p, double seconds) {
+    if (!p) return gab::bad_arg("gab_conv_engine_set_idle_limit: null plan");
+    if (!(seconds >= 0.5 && seconds <= 3600.0)) return gab::bad_arg("gab_conv_engine_set_idle_limit: 0.5 .. 3600 seconds");
+    if (p->eng_running) return gab::bad_arg("gab_conv_engine_set_idle_limit: the plan's engine is running (it takes the limit at its start)");
+    p->eng_idle_seconds = seconds;
+    return GAB_OK;
+}
+
+// The reference's iteration through the engine (cuda/bench_base.cu:30-42 around bench_conv1d_accel.cu:258-304): pinned host ->
+// ring slot (engine copy), doorbell with the flush rung, wait for that buffer, ring slot -> pinned host (engine copy).  The two
+// link legs do not overlap with the transform (gab_conv_round_trip's do): this is the per-buffer engine as a complete
+// replacement of that iteration with a stated number, not the fastest round trip.
+int gab_conv_engine_round_trip(gab_conv_plan* p, const float* h_in, float* h_out) {
+    return gab::guarded([&]() -> int {
+        if (!p || !h_in || !h_out) return gab::bad_arg("gab_conv_engine_round_trip: null argument");
+        if (!p->eng_running) return gab::bad_arg("gab_conv_engine_round_trip: no running engine (gab_conv_engine_start first)");
+        int done = 0;
+        gab_conv_engine_completed(p, &done);
+        if ((unsigned)done != p->eng_published)
+            return gab::bad_arg("gab_conv_engine_round_trip: buffers are still in flight (ONE buffer at a time: wait for what has been published)");
+        if (!p->eng_copy_stream) {
+            GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->eng_copy_stream, hipStreamNonBlocking));
+            GAB_HIP_CHECK(hipEventCreateWithFlags(&p->eng_copy_ev, hipEventDisableTiming));
+        }
+        const size_t n = (size_t)p->tracks * p->bufsize;
+        const size_t slot = p->eng_published % (unsigned)p->eng_ring;
+        auto spin = [&](const char* what) -> int {          // (an event query: hipStreamSynchronize would yield the thread)
+            GAB_HIP_CHECK(hipEventRecord(p->eng_copy_ev, p->eng_copy_stream));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;;) {
+                const hipError_t q = hipEventQuery(p->eng_copy_ev);
+                if (q == hipSuccess) return GAB_OK;
+                (void)hipGetLastError();
+                if (q != hipErrorNotReady) GAB_HIP_CHECK(q);
+                if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+                    gab::set_last_error(std::string("gab_conv_engine_round_trip: ") + what + " did not end within 4 s (pinned host memory keeps it on a copy engine; "
+                                        "pageable memory may send it through a kernel, which cannot run beside the engine)");
+                    return GAB_ERR_RUNTIME;
+                }
+            }
+        };
+        GAB_HIP_CHECK(hipMemcpyAsync(p->eng_in + slot * n, h_in, n * sizeof(float), hipMemcpyHostToDevice, p->eng_copy_stream));
+        if (int rc = spin("the upload")) return rc;
+        if (int rc = gab_conv_engine_submit(p, 1, 1)) return rc;
+        if (int rc = gab_conv_engine_wait(p, (int)p->eng_published, 5.0)) return rc;
+        GAB_HIP_CHECK(hipMemcpyAsync(h_out, p->eng_out + slot * n, n * sizeof(float), hipMemcpyDeviceToHost, p->eng_copy_stream));
+        return spin("the download");
     });
 }
 

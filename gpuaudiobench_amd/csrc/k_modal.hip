@@ -57,8 +57,11 @@ __device__ __forceinline__ cf mul_by_hi(cf st, cf cs) {
 // order, so that no instruction waits for the one before it: 112 against 113 us, the same.  What the 5-instruction
 // floor (71 us at 2.4 GHz: tools/kernel_table.py) does not hold: the double-precision sincos per mode (~12 %), the folds (~20 %), the clock
 // under packed-fp32 load (~2.2 GHz).)
+// (Run-time track counts, TRACKS == 0: three waves per SIMD and at most four modes per lane — the fold over a track count that is
+// not a power of two holds three chunks of samples at once; under four waves' 128 registers four modes per lane spilled 16 bytes
+// per lane and eight 612, and eight still spill with 256 registers: modal_launch stops at four there.)
 template <int J, int TRACKS>
-__global__ __launch_bounds__(kMbThreads, 4) void modal_bank_kernel(const float* __restrict__ params,
+__global__ __launch_bounds__(kMbThreads, TRACKS > 0 ? 4 : 2) void modal_bank_kernel(const float* __restrict__ params,
                                                                float* __restrict__ partial,
                                                                int n_modes, int tracks_rt, int B) {
     const int tracks = TRACKS > 0 ? TRACKS : tracks_rt;
@@ -203,8 +206,9 @@ ModalLaunch modal_launch(int n_modes, int tracks) {
     const int slots = 64 / tracks;
     const long rows = ((long)n_modes + tracks - 1) / tracks;
     const long rows_per_wg1 = (long)kMbWaves * slots;
+    const int Jmax = tracks == 32 ? 8 : 4;          // (the compile-time track count's instantiations go to eight: see the kernel)
     int J = 1;
-    while (J < 8 && (rows + rows_per_wg1 * J - 1) / (rows_per_wg1 * J) > 256) J *= 2;
+    while (J < Jmax && (rows + rows_per_wg1 * J - 1) / (rows_per_wg1 * J) > 256) J *= 2;
     const long grid = (rows + rows_per_wg1 * J - 1) / (rows_per_wg1 * J);
     return {J, kMbThreads, (int)(grid < 1 ? 1 : grid)};
 }
@@ -243,7 +247,9 @@ int gab_modal_bank(const float* d_params, float* d_out, int n_modes, int bufsize
         switch (L.J) {
             case 1: GAB_MODAL_LAUNCH(1); break;
             case 2: GAB_MODAL_LAUNCH(2); break;
-            case 8: GAB_MODAL_LAUNCH(8); break;
+            case 8:                                  // 32 tracks only (modal_launch)
+                gab::modal_bank_kernel<8, 32><<<L.grid, L.threads, 0, s>>>(d_params, d_workspace, n_modes, out_tracks, bufsize);
+                break;
             default: GAB_MODAL_LAUNCH(4); break;
         }
 #undef GAB_MODAL_LAUNCH

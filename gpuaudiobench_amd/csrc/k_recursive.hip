@@ -9,6 +9,7 @@
 // delay-line cells.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 
 #include <cstdint>
 
@@ -763,19 +764,31 @@ constexpr int kDwgSlots = 16;
 constexpr int kDwgMaxB = 2048;
 __device__ int g_dwg_count[kDwgSlots][kDwgMaxB];      // hits per sample; zero between calls
 
-template <int U>
+// STAGED = true is round 5's form (U = 8): the buffer's input staged in LDS behind a barrier, 2048 workgroups at 8192 lines —
+// EIGHT per compute unit where seven fit (61 registers), so the launch ran two rounds of a chain of three dependent round
+// trips (input -> LDS -> barrier; the lines' records; their cells): 20.1 us for 67 MB.  STAGED = false (round 6): no LDS and
+// no barrier — a thread's first sample x[s0] is one coalesced load requested beside the records (every line of 512 cells and
+// more uses no other; shorter lines fetch their later samples from the L1/L2 as they go) — and U = 16 lines per workgroup:
+// 1024 workgroups, four per compute unit, ONE round, twice the cell loads in flight per thread.  Same operations per cell in
+// the same order: bit-identical (test_dwg_large_bank_*).
+template <int U, bool STAGED>
 __global__ __launch_bounds__(256) void dwg_cells_append_kernel(const WG* __restrict__ wgs,
                                                               float* __restrict__ fwd, float* __restrict__ bwd,
                                                               const float* __restrict__ input,
                                                               float* __restrict__ ws, int2* __restrict__ hits,
                                                               int2* __restrict__ mix_list, int n_wg, int n_mix, int B,
                                                               int max_len, int slot) {
-    __shared__ float xin[kDwgMaxB];
+    __shared__ float xin[STAGED ? kDwgMaxB : 1];
     int* const count = g_dwg_count[slot];
     const int g0 = blockIdx.y * U;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) xin[i] = input[i];
-    __syncthreads();
     const int s0 = blockIdx.x * blockDim.x + threadIdx.x;
+    float x0 = 0.0f;
+    if constexpr (STAGED) {
+        for (int i = threadIdx.x; i < B; i += blockDim.x) xin[i] = input[i];
+        __syncthreads();
+    } else {
+        if (s0 < B) x0 = input[s0];
+    }
     WG wg[U];
     float f[U], b[U];
     float* F[U];
@@ -808,7 +821,7 @@ __global__ __launch_bounds__(256) void dwg_cells_append_kernel(const WG* __restr
         const bool inject = (p == wg[u].inTap), tap = (p == wg[u].outTap);
         float mix;
         for (int s = s0; s < B; s += wg[u].length) {
-            float x = __fmul_rn(xin[s], wg[u].gain);
+            float x = __fmul_rn(STAGED ? xin[s] : (s == s0 ? x0 : input[s]), wg[u].gain);
             dwg_step(f[u], b[u], x, inject, wg[u], mix);
             if (tap) {
                 ws[(size_t)g * B + s] = mix;                        // (the crowded-sample scan's copy)
@@ -934,18 +947,43 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
             int cells = max_len < bufsize ? max_len : bufsize;   // a buffer visits min(L, B) cells of a line
             constexpr int U = 8;
             if (sparse && bufsize <= gab::kDwgMaxB) {            // large banks: the cells kernel appends to the hit lists itself
-                static std::atomic<unsigned> next_slot{0};
-                const int slot = (int)(next_slot.fetch_add(1) % (unsigned)gab::kDwgSlots);
+                // The per-sample counters live in a pool of kDwgSlots zeroed arrays in the code object; a call takes the next
+                // slot and its mix kernel zeroes it again.  What keeps a slot from being taken twice at once (more than
+                // kDwgSlots calls in flight over several streams) is an event per slot: a call on ANOTHER stream goes behind
+                // the slot's last user; a mix launch that fails zeroes the slot itself.
+                struct Slot { hipEvent_t busy = nullptr; hipStream_t last = nullptr; bool used = false; };
+                static Slot slots[gab::kDwgSlots];
+                static std::mutex slots_mu;
+                static unsigned next_slot = 0;
+                int form = 2;                                    // 0: round 5's (U = 8, staged input); 1: U = 8; 2: U = 16
+#ifdef GAB_ABLATE
+                if (getenv("GAB_DWG_FORM")) form = atoi(getenv("GAB_DWG_FORM"));     // diagnostic builds: A/B on one box
+#endif
                 int* pool = nullptr;
                 GAB_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&pool), HIP_SYMBOL(gab::g_dwg_count)));
-                dim3 grid((cells + 255) / 256, (n_waveguides + U - 1) / U);
-                gab::dwg_cells_append_kernel<U><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, n_waveguides,
-                                                                     n_mix, bufsize, max_len, slot);
+                std::lock_guard<std::mutex> lock(slots_mu);
+                const int slot = (int)(next_slot++ % (unsigned)gab::kDwgSlots);
+                Slot& sl = slots[slot];
+                if (!sl.busy) GAB_HIP_CHECK(hipEventCreateWithFlags(&sl.busy, hipEventDisableTiming));
+                if (sl.used && sl.last != s) GAB_HIP_CHECK(hipStreamWaitEvent(s, sl.busy, 0));
+                const int UU = form == 2 ? 16 : U;
+                dim3 grid((cells + 255) / 256, (n_waveguides + UU - 1) / UU);
+#define GAB_DWG_APPEND(UV, ST) gab::dwg_cells_append_kernel<UV, ST><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, \
+                                                                                n_waveguides, n_mix, bufsize, max_len, slot)
+                if (form == 2) GAB_DWG_APPEND(16, false);
+                else if (form == 1) GAB_DWG_APPEND(U, false);
+                else GAB_DWG_APPEND(U, true);
+#undef GAB_DWG_APPEND
                 int rc = gab::launch_status("dwg_cells_append_kernel");
-                if (rc) return rc;
+                if (rc) return rc;                               // (nothing was appended: the slot is still zero)
                 gab::dwg_mix_kernel<<<(bufsize + 3) / 4, 256, 0, s>>>(hits, ws, d_out, n_waveguides, bufsize, out_tracks,
                                                                       pool + (size_t)slot * gab::kDwgMaxB, mix_list, true);
-                return gab::launch_status("dwg_mix_kernel");
+                rc = gab::launch_status("dwg_mix_kernel");
+                if (rc) (void)hipMemsetAsync(pool + (size_t)slot * gab::kDwgMaxB, 0, sizeof(int) * gab::kDwgMaxB, s);   // the appends stand: nobody else zeroes them
+                sl.used = true;
+                sl.last = s;
+                GAB_HIP_CHECK(hipEventRecord(sl.busy, s));
+                return rc;
             }
             if (n_waveguides >= 1024) {                          // U lines per workgroup (see the kernel)
                 dim3 grid((cells + 255) / 256, (n_waveguides + U - 1) / U);

@@ -80,6 +80,25 @@ def datatransfer(x, out_size):
     return out
 
 
+def _placement(fn, handle):
+    import numpy as np
+    cap = 256
+    hw, xc = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    n = C.c_int(0)
+    check(fn(handle, hw.ctypes.data_as(C.c_void_p), xc.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+    return [dict(xcc=int(x & 0xf), se=int((h >> 13) & 7), sa=int((h >> 12) & 1), cu=int((h >> 8) & 0xf),
+                 simd=int((h >> 4) & 3), slot=int(h & 0xf)) for h, x in zip(hw[:n.value], xc[:n.value])]
+
+
+def placement_summary(places):
+    """'8 waves on 8 XCDs: x0/se1/cu3 ...' — one line for a measurement's record."""
+    if not places:
+        return "no wave has started"
+    return "%d waves on %d XCDs: %s" % (len(places), len({p["xcc"] for p in places}),
+                                        " ".join("x%d/se%d/cu%d" % (p["xcc"], p["se"], p["cu"]) for p in places[:16]) +
+                                        (" ..." if len(places) > 16 else ""))
+
+
 class KeepWarm:
     """gab_keep_warm: a small resident launch that keeps the device from going idle between real-time slots
     (kick() once per slot; it ends by itself idle_seconds after the last kick)."""
@@ -96,6 +115,11 @@ class KeepWarm:
         v = C.c_int(0)
         check(lib.gab_keep_warm_running(self._h, C.byref(v)))
         return bool(v.value)
+
+    def placement(self):
+        """Where the waves of the current (or last) launch landed: a list of dicts (xcc, se, sa, cu, simd, slot) for every
+        wave that has started (gab_keep_warm_placement; HW_ID / XCC_ID as the hardware reports them)."""
+        return _placement(lib.gab_keep_warm_placement, self._h)
 
     def close(self):
         if self._h:
@@ -260,6 +284,10 @@ class ConvPlan:
         """Every later round trip of this plan ends with a keep-warm kick (gab_conv_round_trip_keep_warm)."""
         check(lib.gab_conv_round_trip_keep_warm(self._h, 1 if on else 0))
 
+    def round_trip_keep_warm_placement(self):
+        """KeepWarm.placement() of the plan's own keep-warm launch ([] if it has none)."""
+        return _placement(lib.gab_conv_round_trip_keep_warm_placement, self._h)
+
     def newest_block(self):
         """The block the plan consumed last ([tracks*512], the input's layout), from its history ring
         (gab_conv_newest_block): what a round trip's upload hand-off is checked against."""
@@ -329,6 +357,16 @@ class ConvPlan:
 
     def engine_stop(self):
         check(lib.gab_conv_engine_stop(self._h))
+
+    def engine_round_trip(self, h_in, h_out):
+        """Pinned host -> ring slot -> engine (flush rung, ONE buffer in flight) -> ring slot -> pinned host
+        (gab_conv_engine_round_trip): the reference's iteration through the resident engine."""
+        assert h_in.is_pinned() and h_out.is_pinned() and h_in.numel() == h_out.numel() == self.tracks * self.bufsize
+        check(lib.gab_conv_engine_round_trip(self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr())))
+
+    def engine_set_idle_limit(self, seconds):
+        """How long a stalled engine waits for the doorbell before it ends by itself (taken at the next start)."""
+        check(lib.gab_conv_engine_set_idle_limit(self._h, float(seconds)))
 
     def process_batch(self, x, n_buffers, out=None):
         """n_buffers consecutive buffers ([n][T*B] in, [n][B*T] out) in one launch."""

@@ -38,6 +38,28 @@ def shard_granule(name):
     return GRANULE.get(name, 1)
 
 
+def bank_bytes_received(ir_len, total_tracks, rank, world, granule=1, distribution="broadcast", src=0):
+    """Bytes of impulse-response bank that arrive at `rank` over the collective of broadcast_ir_bank: the whole bank
+    under "broadcast", its own rows under "slices", nothing at `src` (which generates it) or without a group."""
+    if world <= 1 or rank == src:
+        return 0
+    if distribution == "broadcast":
+        return 4 * total_tracks * ir_len
+    lo, hi = shard_range(rank, world, total_tracks, granule)
+    return 4 * (hi - lo) * ir_len
+
+
+def gather_per_rank(values, rank, world, dist=None, device="cpu"):
+    """Every rank's list of floats, as a list of lists on every rank (all_gather over the job's group; a job without a
+    group is one rank).  For rank 0's result line: a straggler rank or a slow bank distribution then names itself."""
+    if dist is None or world <= 1:
+        return [list(map(float, values))]
+    t = torch.tensor(list(map(float, values)), dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.cpu()] for o in out]
+
+
 def broadcast_ir_bank(ir_len, total_tracks, rank, world, device, dist=None, src=0, granule=1, distribution="broadcast"):
     """Returns this rank's slice (tracks x ir_len, contiguous, on `device`) of the
     global conv1d_accel bank.  Rank `src` generates the whole bank.

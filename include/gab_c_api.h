@@ -97,14 +97,23 @@ int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h
  * gab_conv_round_trip_keep_warm(plan, 1) makes every gab_conv_round_trip of that plan end with a kick (0: no more kicks,
  * the launch ends idle_seconds later; the plan owns the object: 8 workgroups, idle limit = eight buffer periods at
  * 44.1 kHz, at least 0.05 s).
- * NOT beside a resident engine: gab_conv_engine_start needs every compute unit whole (its workgroup fills the register files), so
- * with keep-warm waves on eight of them it cannot become resident until they have ended — stop kicking (or destroy the object)
- * first; the engine keeps the device awake itself, and gab_conv_engine_start drops the plan's own keep-warm.
- * One thread at a time per object (like a plan).  gab_keep_warm_running: is the launch on the device right now?                */
+ * NOT beside a resident engine, and the library enforces it (it makes every keep-warm launch and every engine, so it knows):
+ * gab_conv_engine_start needs every compute unit whole (its workgroup fills the register files) — with keep-warm waves on eight of
+ * them its first buffer waited out their idle limit (484 ms on record).  gab_conv_engine_start drops the plan's OWN keep-warm and
+ * returns GAB_ERR_INVALID_ARG while any other keep-warm launch is running on the device (destroy the object, or let it run out);
+ * gab_keep_warm_kick returns GAB_ERR_INVALID_ARG when it would have to START a launch while an engine is resident on the device.
+ * The engine keeps the device awake itself.
+ * Workgroup 0 of the launch alone decides that it has been idle long enough; the other waves leave when it says so.
+ * One thread at a time per object (like a plan).  gab_keep_warm_running: is the launch on the device right now?
+ * gab_keep_warm_placement: where the waves of the current (or last) launch landed — for each wave that has started, the raw
+ * HW_ID register (gfx9 layout: bits 3:0 wave slot, 5:4 SIMD, 11:8 compute unit, 12 shader array, 15:13 shader engine) and the
+ * XCC_ID register (bits 3:0: the XCD); `*started` = how many have (of `workgroups`); at most `capacity` pairs are written.
+ * Eight waves are meant to sit on eight XCDs: a paced measurement that prints this beside its p50 classifies itself.          */
 typedef struct gab_keep_warm gab_keep_warm;
 int gab_keep_warm_create(gab_keep_warm** out, int workgroups, double idle_seconds);
 int gab_keep_warm_kick(gab_keep_warm* warm);
 int gab_keep_warm_running(gab_keep_warm* warm, int* running);
+int gab_keep_warm_placement(gab_keep_warm* warm, unsigned* hw_id, unsigned* xcc_id, int capacity, int* started);
 int gab_keep_warm_destroy(gab_keep_warm* warm);
 
 /* IIRFilterKernel (cuda/bench_iir.cu:10-44): DF-II biquad per track,
@@ -266,6 +275,8 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
 int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
 /* Every later gab_conv_round_trip of this plan ends with a gab_keep_warm_kick (see keep-warm above); on = 0 stops kicking. */
 int gab_conv_round_trip_keep_warm(gab_conv_plan* plan, int on);
+/* gab_keep_warm_placement of the plan's own keep-warm launch (started = 0 if the plan has none). */
+int gab_conv_round_trip_keep_warm_placement(gab_conv_plan* plan, unsigned* hw_id, unsigned* xcc_id, int capacity, int* started);
 /* The block the plan consumed LAST, as its kernels keep it (the newest slot of the history ring of a 512-sample
  * plan), written to d_out in the input's layout [tracks][512].  An inspection call (additive): after
  * gab_conv_round_trip it must equal that call's h_in word for word — the check of the upload hand-off that tests
@@ -299,14 +310,26 @@ int gab_conv_newest_block(gab_conv_plan* plan, float* d_out, gab_stream_t stream
  *   feed      a host loop for resident rings: rings the doorbell n_buffers times, one buffer each, never more than
  *             `ahead` (6 <= ahead < ring_buffers) in front of `completed`;
  *   stop      rings the stop bit, waits for the launch to end (every published buffer is finished), carries the
- *             history on for the next gab_conv_process / batch / engine.
+ *             history on for the next gab_conv_process / batch / engine;
+ *   round_trip   the reference's iteration through the engine (cuda/bench_base.cu:30-42 around bench_conv1d_accel.cu:258-304),
+ *             ONE buffer in flight: engine copy of h_in (pinned host, [T*B]) into the next ring slot, submit(1, flush), wait for
+ *             that buffer, engine copy of its slot into h_out (pinned host, [B*T]).  Same bits as gab_conv_process.  The two link
+ *             legs do not overlap with the transform — gab_conv_round_trip's do, and it is the faster round trip; this entry makes
+ *             the per-buffer engine a complete replacement of that iteration.  Nothing else may be in flight;
+ *   set_idle_limit   how long a stalled engine waits for the doorbell to move before it ends by itself (default 4 s; 0.5 .. 3600;
+ *             taken at the next start).  A real-time caller that may pause for longer than that between buffers raises it.
  * The device is the engine's while it runs (256 workgroups at 1024 channels): other kernels queue behind it — and with
  * FEWER channels a kernel on another stream may still wait until stop: the runtime maps streams onto a few hardware
  * queues, and a kernel (a device-to-device copy is one) that lands on the engine's queue stands behind the resident
  * launch.  Only copy ENGINES (pinned host <-> device copies) are sure to move the rings while the launch runs.  Every
  * workgroup of the engine must be resident at once: start refuses a plan with more channels than 4 x the workgroups the
  * device holds (1024 channels on MI355X; more channels: one engine per device over channel shards).  If the
- * doorbell does not move for a few seconds (2-6) the launch ends by itself and stop / feed / wait return GAB_ERR_RUNTIME. */
+ * doorbell does not move for the idle limit (4 s unless set) the launch ends by itself and stop / feed / wait return
+ * GAB_ERR_RUNTIME; stop then carries the plan's history on from what the engine CONSUMED (its message says how many of the
+ * published buffers that is): a pipelined burst without the flush rung leaves its last buffer unconsumed — publish it again
+ * after the next start.  start returns GAB_ERR_INVALID_ARG while a keep-warm launch other than the plan's own is resident on
+ * the device (see keep-warm above).  A wait that runs out says in gab_last_error whether the launch ever became resident
+ * (never started / only some workgroups / all of them), so a hardware-queue collision or a crowded device names itself.       */
 int gab_conv_engine_rings(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring);
 int gab_conv_engine_start(gab_conv_plan* plan, int ring_buffers, float** d_in_ring, float** d_out_ring, gab_stream_t stream);
 int gab_conv_engine_publish(gab_conv_plan* plan, int n_more);
@@ -318,6 +341,8 @@ int gab_conv_engine_completed(gab_conv_plan* plan, int* completed);
 int gab_conv_engine_feed(gab_conv_plan* plan, int n_buffers, int ahead);
 int gab_conv_engine_feed_one_in_flight(gab_conv_plan* plan, int n_buffers, float* latency_us);
 int gab_conv_engine_stop(gab_conv_plan* plan);
+int gab_conv_engine_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out);
+int gab_conv_engine_set_idle_limit(gab_conv_plan* plan, double seconds);
 /* Bytes of device state the plan holds: spectra, history.                    */
 int gab_conv_state_bytes(const gab_conv_plan* plan, size_t* spectra_bytes,
                          size_t* history_bytes);

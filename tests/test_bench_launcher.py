@@ -28,6 +28,9 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["config"]["ir_broadcast_ms"] is not None
     assert d["config"]["ir_slices_match_global_bank"] is True
     assert d["value"] is None and "DRY RUN" in d["data"]          # never mistaken for a measurement
+    # rank 0's line carries every rank's own figures: the source receives nothing, rank 1 the whole bank (16 x 64 taps)
+    pr = d["config"]["per_rank"]
+    assert pr["ir_bytes_received"] == [0, 4 * 16 * 64] and len(pr["ir_broadcast_ms"]) == 2 and all(v >= 0 for v in pr["ir_broadcast_ms"])
 
 
 def test_bench_single_rank_needs_no_launcher():
@@ -54,3 +57,5 @@ def test_bench_gpus_8_dry_run_at_c5_shapes():
     assert d["n_gpus"] == 8 and d["config"]["channels_total"] == 8192 and d["config"]["channels_per_rank"] == 1024
     assert d["config"]["taps"] == 4096 and d["config"]["ir_distribution"] == "slices"
     assert d["config"]["ir_slices_match_global_bank"] is True
+    pr = d["config"]["per_rank"]                       # 16 MiB of rows per rank instead of the 128 MiB bank
+    assert pr["ir_bytes_received"] == [0] + [4 * 1024 * 4096] * 7 and len(pr["ir_broadcast_ms"]) == 8

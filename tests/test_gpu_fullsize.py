@@ -439,3 +439,7 @@ def test_bench_under_a_launcher_walks_the_rccl_path_on_one_gpu(ranks, distributi
     assert d["config"]["ir_distribution"] == distribution and d["config"]["channels_total"] == 1024 * ranks
     assert d["config"]["ir_broadcast_ms"] is not None and d["config"]["ir_broadcast_ms"] >= 0
     assert d["parity_checked"]["ok"] is True and d["value"] > 0
+    pr = d["config"]["per_rank"]                       # every rank's own launch period, bank time and bytes received
+    assert len(pr["us_per_buffer"]) == ranks and all(v > 0 for v in pr["us_per_buffer"]) and len(pr["ir_broadcast_ms"]) == ranks
+    bank = 4 * 4096 * 1024 * ranks
+    assert pr["ir_bytes_received"] == ([0] if ranks == 1 else [0, bank if distribution == "broadcast" else bank // 2])

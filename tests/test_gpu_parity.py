@@ -532,7 +532,15 @@ def test_keep_warm_launch_comes_and_goes_and_changes_no_bits(gab, orc):
     b.close()                                            # its launch is still there: the stop word ends it
     w.close()
     w = gab.KeepWarm(workgroups=8, idle_seconds=2.0)
+    assert w.placement() == []                           # nothing has started
     w.kick()
+    t0 = time.perf_counter()
+    while len(w.placement()) < 8 and time.perf_counter() - t0 < 2.0:
+        time.sleep(0.001)
+    where = w.placement()                                # every wave says where it landed (HW_ID / XCC_ID)
+    assert len(where) == 8 and all(0 <= p["xcc"] < 8 and 0 <= p["cu"] < 16 for p in where), where
+    assert len({(p["xcc"], p["se"], p["sa"], p["cu"], p["simd"], p["slot"]) for p in where}) == 8, where   # eight different wave slots
+    print("keep-warm placement:", gab.ops.placement_summary(where))
     t0 = time.perf_counter()
     w.close()                                            # the stop word, not the idle limit
     assert time.perf_counter() - t0 < 0.5
@@ -832,9 +840,11 @@ def test_conv_accel_engine_refuses_more_channels_than_stay_resident(gab, orc):
 
 
 def test_conv_accel_engine_whose_producer_goes_away_ends_by_itself_and_says_so(gab, orc):
-    """The doorbell stops moving (the producer published three buffers and left): after about two seconds the resident
-    launch ends by itself, gab_conv_engine_stop returns GAB_ERR_RUNTIME, the device is free again, and after a reset
-    the plan convolves as a fresh one does."""
+    """The doorbell stops moving (the producer published three buffers WITHOUT the flush rung and left): after the idle
+    limit (gab_conv_engine_set_idle_limit, one second here) the resident launch ends by itself, gab_conv_engine_stop
+    returns GAB_ERR_RUNTIME and says what the engine consumed — two of the three: the last buffer of a pipelined burst
+    waits for its successor — and the plan's history goes on from THERE: no reset, the next ordinary launch continues
+    behind buffer 2 bit for bit."""
     import time
     import torch
     T, B, L, R = 64, 512, 4096, 8
@@ -842,23 +852,151 @@ def test_conv_accel_engine_whose_producer_goes_away_ends_by_itself_and_says_so(g
     a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
     a.set_ir(ir)
     b.set_ir(ir)
+    xs = [dev(orc.noise(T * B, seed=i)) for i in range(R)]
     in_ring, out_ring = b.engine_rings(R)
-    in_ring.copy_(torch.cat([dev(orc.noise(T * B, seed=i)) for i in range(R)]).view(R, T * B))
+    in_ring.copy_(torch.cat(xs).view(R, T * B))
     torch.cuda.synchronize()
+    with pytest.raises(gab.GabError):
+        b.engine_set_idle_limit(0.1)                             # 0.5 .. 3600 s
+    b.engine_set_idle_limit(1.0)
     side = torch.cuda.Stream()
     b.engine_start(R, stream=side)
+    with pytest.raises(gab.GabError):
+        b.engine_set_idle_limit(2.0)                             # taken at the start: not while it runs
     b.engine_publish(3)
     t0 = time.time()
     while b.engine_running() and time.time() - t0 < 20.0:        # the launch must END without a stop (it is on the plan's own stream)
         time.sleep(0.05)
     waited = time.time() - t0
     assert not b.engine_running(), "the engine was still running after %.1f s without a doorbell" % waited
-    assert 1.0 < waited < 15.0, waited
-    with pytest.raises(gab.GabError):
+    assert 0.5 < waited < 6.0, waited
+    with pytest.raises(gab.GabError) as e:
         b.engine_stop()
-    b.reset()
+    assert "consumed 2 of the 3" in str(e.value), str(e.value)
+    assert b.engine_completed() == 2
+    want = [a.process(xs[k]) for k in range(3)]
+    assert torch.equal(out_ring[0].view(torch.int32), want[0].view(torch.int32))
+    assert torch.equal(out_ring[1].view(torch.int32), want[1].view(torch.int32))
+    assert torch.equal(b.process(xs[2]).view(torch.int32), want[2].view(torch.int32))     # the history continues behind what was CONSUMED
     x = dev(orc.noise(T * B, seed=77))
     assert torch.equal(a.process(x).view(torch.int32), b.process(x).view(torch.int32))
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("T", [64, 1024])
+def test_conv_accel_engine_and_keep_warm_exclude_each_other_at_the_call(gab, orc, T):
+    """The engine's workgroup fills a compute unit's registers, so keep-warm waves keep it from becoming resident (round 5's
+    record: first buffer 484 ms).  The library makes both launches, so it says so at the failing call
+    (cuda/bench_base.cu:177-179: errors where they happen): gab_conv_engine_start drops the PLAN'S OWN keep-warm — its first
+    buffer, one in flight, then answers in well under a slot and bit for bit — and refuses while a keep-warm object the
+    CALLER made is resident; gab_keep_warm_kick refuses to start a launch beside a running engine."""
+    import time
+    import torch
+    B, L, R = 512, 4096, 8
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="classic")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    xs = [orc.noise(T * B, seed=900 + i) for i in range(8)]
+    h_in, h_out = torch.empty(T * B).pin_memory(), torch.empty(T * B).pin_memory()
+    b.round_trip_keep_warm(True)
+    for k in range(3):                                           # the classic cut's round trips, each ending with a kick
+        h_in.copy_(torch.from_numpy(xs[k]))
+        b.round_trip(h_in, h_out)
+    b.reset()
+    b.set_scheme("split")
+    want = [host(a.process(dev(x), mode=gab.CONV_STREAMING)) for x in xs]
+    side = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    in_ring, out_ring = b.engine_start(R, stream=side)           # the plan's keep-warm launch was kicked microseconds ago
+    h_in.copy_(torch.from_numpy(xs[0]))
+    in_ring[0].copy_(h_in, non_blocking=True)
+    cur.synchronize()
+    t0 = time.perf_counter()
+    b.engine_submit(1, flush=True)
+    b.engine_wait(1, timeout=8.0)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    assert first_ms < 5.0, "the engine's first buffer took %.3f ms: something kept its workgroups out" % first_ms
+    h_out.copy_(out_ring[0], non_blocking=True)
+    cur.synchronize()
+    assert np.array_equal(bits(h_out.numpy()), bits(want[0]))
+    w = gab.KeepWarm(workgroups=8, idle_seconds=2.0)
+    with pytest.raises(gab.GabError) as e:
+        w.kick()                                                 # would have to START a launch beside the engine
+    assert "engine" in str(e.value)
+    assert not w.running()
+    b.engine_stop()
+    w.kick()
+    assert w.running()
+    with pytest.raises(gab.GabError) as e:
+        b.engine_start(R, stream=side)                           # a keep-warm the CALLER made: refused, not a 0.5 s stall
+    assert "gab_keep_warm" in str(e.value), str(e.value)
+    assert not b.engine_running()
+    w.close()
+    in_ring, out_ring = b.engine_start(R, stream=side)           # slots count from 0 again
+    for k in (1, 2):
+        h_in.copy_(torch.from_numpy(xs[k]))
+        in_ring[(k - 1) % R].copy_(h_in, non_blocking=True)
+        cur.synchronize()
+        b.engine_submit(1, flush=True)
+        b.engine_wait(k, timeout=8.0)
+        h_out.copy_(out_ring[(k - 1) % R], non_blocking=True)
+        cur.synchronize()
+        assert np.array_equal(bits(h_out.numpy()), bits(want[k])), "buffer %d" % k
+    b.engine_stop()
+    a.close()
+    b.close()
+
+
+def test_conv_accel_engine_wait_that_runs_out_says_where_the_launch_is(gab, orc):
+    """A wait that runs out names the state of the launch (gab_last_error): here every workgroup is resident and the ONE
+    published buffer waits for a successor or the flush rung — the message says so; with the rung it completes."""
+    import torch
+    T, B, L, R = 64, 512, 4096, 8
+    b = gab.ConvPlan(T, B, L, scheme="split")
+    b.set_ir(dev(orc.conv_accel_ir(L, T)))
+    in_ring, out_ring = b.engine_rings(R)
+    in_ring.copy_(torch.cat([dev(orc.noise(T * B, seed=i)) for i in range(R)]).view(R, T * B))
+    torch.cuda.synchronize()
+    b.engine_start(R, stream=torch.cuda.Stream())
+    b.engine_publish(1)
+    with pytest.raises(gab.GabError) as e:
+        b.engine_wait(1, timeout=0.5)
+    assert "every workgroup of the launch is resident" in str(e.value), str(e.value)
+    b.engine_submit(0, flush=True)
+    b.engine_wait(1, timeout=8.0)
+    b.engine_stop()
+    b.close()
+
+
+@pytest.mark.parametrize("T", [64, 1024])
+def test_conv_accel_engine_round_trip_from_pinned_host_memory(gab, orc, T):
+    """gab_conv_engine_round_trip: the reference's iteration (cuda/bench_base.cu:30-42 around bench_conv1d_accel.cu:258-304)
+    through the resident engine — pinned host -> ring slot, doorbell with the flush rung, ring slot -> pinned host, ONE
+    buffer in flight — bit for bit one gab_conv_process launch per buffer, more buffers than the ring has slots, and
+    refused while something else is in flight."""
+    import torch
+    B, L, R, N = 512, 4096, 4, 11
+    ir = dev(orc.conv_accel_ir(L, T))
+    a, b = gab.ConvPlan(T, B, L, scheme="split"), gab.ConvPlan(T, B, L, scheme="split")
+    a.set_ir(ir)
+    b.set_ir(ir)
+    xs = [orc.noise(T * B, seed=1200 + i) for i in range(N)]
+    want = [host(a.process(dev(x), mode=gab.CONV_STREAMING)) for x in xs]
+    h_in, h_out = torch.empty(T * B).pin_memory(), torch.empty(T * B).pin_memory()
+    with pytest.raises(gab.GabError):
+        b.engine_round_trip(h_in, h_out)                         # no running engine
+    b.engine_start(R, stream=torch.cuda.Stream())
+    for k in range(N):
+        h_in.copy_(torch.from_numpy(xs[k]))
+        h_out.zero_()
+        b.engine_round_trip(h_in, h_out)
+        assert np.array_equal(bits(h_out.numpy()), bits(want[k])), "buffer %d" % k
+    b.engine_publish(1)                                          # something in flight that nobody waited for
+    with pytest.raises(gab.GabError):
+        b.engine_round_trip(h_in, h_out)
+    b.engine_stop()
     a.close()
     b.close()
 

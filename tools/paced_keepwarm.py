@@ -76,14 +76,17 @@ def with_keep_warm(wgs, naps, label=None):
     warm.kick()
     ts, missed = paced(after=warm.kick)
     alive = warm.running()
+    where = gab.ops.placement_summary(warm.placement())          # where the waves landed: a run that buys nothing classifies itself
     warm.close()
     line((label or "paced, keep-warm: %3d waves, a look every %d naps" % (wgs, naps)) + (" [launch alive: %s]" % alive), ts, missed)
+    print("%-64s %s" % ("", where), flush=True)
 
 
 def with_switch(between=None, label="paced, gab_conv_round_trip_keep_warm(plan, 1)"):
     rplan.round_trip_keep_warm(True)                            # the product's switch: 8 waves, kicked by the call itself
     rplan.launch_round_trip(args)
     line(label, *paced(between))
+    print("%-64s %s" % ("", gab.ops.placement_summary(rplan.round_trip_keep_warm_placement())), flush=True)
     rplan.round_trip_keep_warm(False)
     time.sleep(0.4)
 
