@@ -168,10 +168,13 @@ struct LinkRoundTrip {
     unsigned* counter;            // device: workgroups finished, runs on from call to call
     unsigned* done;               // pinned host: the epoch, once every workgroup has finished (a HINT: the call waits for the launch's end)
     const unsigned* landed;       // pinned host: the epoch, once the host has seen the upload complete
-    unsigned* error;              // pinned host: nonzero if a wait ran out
+    unsigned* error;              // pinned host: bit 0 a wait ran out, bit 1 a consumed word is not what the completed upload left
+    unsigned* consumed;           // device: [>= in_size] the words as the kernel took them, until they have been checked
+    unsigned* relay;              // device: `landed` as workgroup 0 last saw it
     unsigned epoch;
     int in_size, out_size;
 };
+constexpr unsigned kLinkErrWait = 1u, kLinkErrTorn = 2u;
 
 __device__ __forceinline__ unsigned link_peek(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -184,9 +187,10 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
     const int chunks = (rt.out_size + kLinkChunk - 1) / kLinkChunk;
     const int dep_chunks = (dep + kLinkChunk - 1) / kLinkChunk;      // chunks that hold at least one input word
     const int free_chunks = chunks - dep_chunks;
-    bool gave_up = false;
+    bool gave_up = false, took = false;
     for (int pos = blockIdx.x; pos < chunks; pos += gridDim.x) {
         const int chunk = pos < free_chunks ? dep_chunks + pos : pos - free_chunks;
+        took = took || chunk < dep_chunks;                            // (uniform over the workgroup)
         const int w0 = chunk * kLinkChunk + 4 * tid;                  // this thread's four words
         const int n_in = max(0, min(4, dep - w0));                    // how many of them are input words
         unsigned w[4] = {0, 0, 0, 0};
@@ -222,8 +226,9 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
                 if (tries > kLinkPollLimit) { gave_up = true; break; }
                 __builtin_amdgcn_s_sleep(10);
             }
-            for (int k = 0; k < 4; ++k)                               // taken: the sentinel goes back for the next call
-                if (k < n_in) __hip_atomic_store(rt.stage + w0 + k, kLinkSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // taken — and kept beside the staging buffer until they have been checked against the completed upload (below)
+            for (int k = 0; k < 4; ++k)
+                if (k < n_in) rt.consumed[w0 + k] = w[k];
         }
         typedef float f4v __attribute__((ext_vector_type(4)));
         f4v val;
@@ -242,13 +247,48 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
     }
     // every wave waits for its rows, then the workgroup counts as finished; the one whose count completes the launch
     // writes the hint word (the host then waits for the launch's END: completion is the stream's, not this word's)
-    if (gave_up) __hip_atomic_store(rt.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (gave_up) __hip_atomic_store(rt.error, kLinkErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(rt.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == rt.epoch * gridDim.x) __hip_atomic_store(rt.done, rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // ---- round 6: what was consumed EARLY against what the COMPLETED upload left (k_conv_accel.hip, rt_landed: the hand-off
+    // rests on engine writes landing whole and once — an observation; a violation must not be silent).  Behind the acquire of
+    // the host's `landed` (workgroup 0's first wave asks the host and passes it on, the others ask the relay) every input
+    // word this workgroup took is read again and compared with the copy it kept; only then does the sentinel go back.
+    // The outputs have left and the hint word is out: this runs beside the last workgroups' rows, before the launch's end.
+    const bool ask_host = blockIdx.x == 0 && tid < kWave;
+    if (!gave_up && dep_chunks > 0 && (took || blockIdx.x == 0)) {   // (workgroup 0 passes the word on whether it took input or not)
+        int tries = 0;
+        for (;;) {
+            bool in_ = false;
+            if (ask_host) {
+                const unsigned h = __hip_atomic_load(rt.landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (h == rt.epoch) { __hip_atomic_store(rt.relay, h, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); in_ = true; }
+            } else {
+                in_ = __hip_atomic_load(rt.relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == rt.epoch;
+            }
+            if (in_) break;
+            if (++tries > kLinkPollLimit) { gave_up = true; break; }
+            if (ask_host) __builtin_amdgcn_s_sleep(30); else __builtin_amdgcn_s_sleep(10);
+        }
+        if (gave_up) __hip_atomic_store(rt.error, kLinkErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    bool torn = false;
+    for (int pos = blockIdx.x; pos < chunks; pos += gridDim.x) {
+        const int chunk = pos < free_chunks ? dep_chunks + pos : pos - free_chunks;
+        if (chunk >= dep_chunks) continue;
+        const int w0 = chunk * kLinkChunk + 4 * tid;
+        const int n_in = max(0, min(4, dep - w0));
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n_in) continue;
+            if (!gave_up) torn = torn || link_peek(rt.stage + w0 + k) != rt.consumed[w0 + k];
+            __hip_atomic_store(rt.stage + w0 + k, kLinkSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the sentinel goes back for the next call
+        }
+    }
+    if (torn) __hip_atomic_fetch_or(rt.error, kLinkErrTorn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- modal (placeholder semantics) ---------------------------------------------
@@ -418,7 +458,9 @@ struct gab_link_plan {
     // input words an earlier call uploaded but did not consume (its input was longer than its output): they hold
     // data, not the sentinel, and a later call that reads them must find the sentinel first
     int stale_lo = 0, stale_hi = 0;
+    unsigned* consumed = nullptr;       // device: the words as the kernel took them (checked against the completed upload)
     ~gab_link_plan() {
+        if (consumed) (void)hipFree(consumed);
         if (stage) (void)hipFree(stage);
         if (counter) (void)hipFree(counter);
         if (words) (void)hipHostFree(words);
@@ -438,8 +480,9 @@ int gab_link_plan_create(int max_in_size, gab_link_plan** out) {
         const size_t n = (size_t)std::max(max_in_size, 4);
         GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->stage), n * 4, hipDeviceMallocFinegrained));
         GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, n));
-        GAB_HIP_CHECK(hipMalloc(&p->counter, 128));
-        GAB_HIP_CHECK(hipMemset(p->counter, 0, 128));
+        GAB_HIP_CHECK(hipMalloc(&p->consumed, n * 4));
+        GAB_HIP_CHECK(hipMalloc(&p->counter, 256));                    // [0] workgroups finished, [32] the relayed `landed`: a line each
+        GAB_HIP_CHECK(hipMemset(p->counter, 0, 256));
         GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->words), 64 * sizeof(unsigned), hipHostMallocDefault));
         for (int i = 0; i < 64; ++i) p->words[i] = 0;
         GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
@@ -527,7 +570,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         volatile unsigned* const done = p->words;
         unsigned* const landed = p->words + 16;
         volatile unsigned* const error = p->words + 32;
-        gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, epoch, in_size, out_size};
+        gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, p->consumed, p->counter + 32, epoch, in_size, out_size};
         // the launch carries its own stop event: what the call returns on (k_conv_accel.hip, kRtCompletion: the cheapest of
         // the stated ways to learn that a launch has ended, profiles/r05_roundtrip_completion.txt)
         hipExtLaunchKernelGGL(gab::datatransfer_round_trip_kernel, dim3(p->workgroups), dim3(gab::kBlock), 0, s, nullptr, p->done_ev, 0, rt);
@@ -584,9 +627,12 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             }
         }
         if (*error != 0 || *done != epoch) {
+            const bool torn = (*error & gab::kLinkErrTorn) != 0;
             *error = 0;
             repoison();
-            gab::set_last_error("gab_datatransfer_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
+            gab::set_last_error(torn ? "gab_datatransfer_round_trip: a word the kernel consumed while the upload was still running is not the word the completed upload "
+                                       "left in the staging buffer (an engine write that landed in pieces or out of order); the output of this call is invalid"
+                                     : "gab_datatransfer_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
             return GAB_ERR_RUNTIME;
         }
         return GAB_OK;

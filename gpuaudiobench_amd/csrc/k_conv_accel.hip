@@ -634,6 +634,7 @@ constexpr size_t kRtUploadPiece = (size_t(4) << 20) - 256;   // bytes per engine
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
 constexpr int kRtMaxGroups = 40;
+constexpr int kBatchWaves = 12;                    // gab_conv_process_batch on a split plan: conv_split_batch12_kernel (12) or conv_split_batch_kernel (8)
 constexpr size_t kBatchChunk = 256;                // buffers per conv_split_batch_kernel launch at most (see gab_conv_process_batch)
 struct ConvRoundTrip {
     unsigned* stage;                  // [T*B] fine-grained device memory
@@ -642,7 +643,8 @@ struct ConvRoundTrip {
     unsigned* counters;               // device: [32 g + {0,1,2}] arrivals / claims / announced epoch of group g, [32 groups] shares drained
     unsigned* done;                   // pinned host: the epoch, once the last share has been drained (a HINT: the call waits for the launch's end)
     const unsigned* landed;           // pinned host: the epoch, once the host has seen the upload complete
-    unsigned* error;                  // pinned host: nonzero if a wait ran out
+    unsigned* error;                  // pinned host: bit 0 a wait ran out, bit 1 a consumed word is not what the completed upload left (kRtErrTorn)
+    unsigned* relay;                  // device: `landed` as workgroup 0 last saw it (the other workgroups ask this word, not the host)
     unsigned epoch;
     int groups;
     unsigned bound[kRtMaxGroups + 1];   // group g = pairs [bound[g], bound[g + 1]): equal groups, the first and the last cut finer (see gab_conv_round_trip_init)
@@ -661,6 +663,29 @@ __device__ unsigned long long g_rt_stamps[65 * 4];
 
 __device__ __forceinline__ unsigned rt_peek(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Round 6: what a workgroup consumed EARLY is checked against what the COMPLETED upload left.  The hand-off above rests on two
+// observations — an engine packet writes a naturally aligned word whole, and a word never shows an intermediate value — and
+// a violation was silent wrong audio (profiles/r05_incident_torn_word.txt was one: found by a stress run, not by the
+// call).  The consumed words stay in the staging buffer until the host's release of `landed` (the copy's completion: its
+// writes are final and visible) has been ACQUIRED; they are then read again and compared with what was consumed, and only
+// then does the sentinel go back.  A difference sets kRtErrTorn and the call returns GAB_ERR_RUNTIME like a wait that ran out.
+// `landed` lives in pinned host memory: workgroup 0's first wave asks the host and passes the word on through `relay`
+// (device memory), everybody else asks the relay.  The last channel group's workgroups find it set when they park their
+// outputs (the copy ended ten microseconds earlier) and read their words again under the drain; earlier groups wait at
+// their end, off the launch's critical path.
+constexpr unsigned kRtErrWait = 1u, kRtErrTorn = 2u;
+// has the host announced the upload's completion?  (wave-uniform; an ACQUIRE: loads issued after a `true` see the final words)
+__device__ __forceinline__ bool rt_landed(const ConvRoundTrip& rt, bool ask_host) {
+    if (ask_host) {
+        const unsigned h = __hip_atomic_load(rt.landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (h == rt.epoch) {
+            __hip_atomic_store(rt.relay, h, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        return false;
+    }
+    return __hip_atomic_load(rt.relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == rt.epoch;
 }
 
 __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
@@ -751,12 +776,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
         }
     }
     GAB_RT_STAMP_MAX(g, 1);
-    if (gave_up) __hip_atomic_store(rt.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // the words are taken: the sentinel goes back for the next buffer (complete before this launch ends)
-    __hip_atomic_store(const_cast<unsigned*>(row) + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(const_cast<unsigned*>(row) + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (gave_up) __hip_atomic_store(rt.error, kRtErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (the words stay where they are until they have been checked against the completed upload: verify_and_rearm below)
 
     // ---- near partition: [block k-1 | block k]
     cf za[4];
@@ -787,9 +808,48 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
         __hip_atomic_store(p0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // Is the upload known to be complete by now?  (The last groups: yes.)  Then this wave's four words are asked for again
+    // behind the barrier — behind the acquire — and travel under the drain; otherwise at the end.
+    const bool ask_host = blockIdx.x == 0 && tid < kWave;         // workgroup 0's first wave talks to the host
+    const bool landed_at_park = !gave_up && rt_landed(rt, ask_host);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its own stores
     __syncthreads();
+    bool checked_early = false;
+    unsigned v[4] = {0, 0, 0, 0};
+    if (landed_at_park) {
+        checked_early = true;
+        v[0] = rt_peek(row + tid);
+        v[1] = rt_peek(row + tid + kThreads);
+        v[2] = rt_peek(row + kB + tid);
+        v[3] = rt_peek(row + kB + tid + kThreads);
+    }
     GAB_RT_STAMP_MAX(g, 2);
+    // the consumed words against the completed upload's, then the sentinel goes back for the next buffer (before this launch ends)
+    auto verify_and_rearm = [&]() {
+        if (!gave_up) {
+            if (!checked_early) {
+                int tries = 0;
+                while (!rt_landed(rt, ask_host)) {
+                    if (++tries > kRtPollLimit) { gave_up = true; break; }
+                    if (ask_host) __builtin_amdgcn_s_sleep(30); else __builtin_amdgcn_s_sleep(10);
+                }
+                if (gave_up) {
+                    __hip_atomic_store(rt.error, kRtErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    v[0] = rt_peek(row + tid);
+                    v[1] = rt_peek(row + tid + kThreads);
+                    v[2] = rt_peek(row + kB + tid);
+                    v[3] = rt_peek(row + kB + tid + kThreads);
+                }
+            }
+            if (!gave_up && (v[0] != w[0] || v[1] != w[1] || v[2] != w[2] || v[3] != w[3]))
+                __hip_atomic_fetch_or(rt.error, kRtErrTorn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(const_cast<unsigned*>(row) + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(const_cast<unsigned*>(row) + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     // ---- the group's slab goes to the pinned output in whole rows of the group's width, shared out among the group's
     // own workgroups: a slab of `members` pairs is members x 256 float4, one SHARE = 256 consecutive float4 = one per
     // thread.  Words per group (a 128-byte line each): [0] arrivals (runs on from launch to launch), [1] shares claimed
@@ -818,7 +878,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     }
     __syncthreads();
     const int role = s_word;
-    if (role == 0) return;
+    if (role == 0) { verify_and_rearm(); return; }
     const int row_f4 = members / 2;                              // float4 per row (members is even: T % 4 == 0)
     const auto srd = __builtin_amdgcn_make_buffer_rsrc(rt.park, 0, (int)((size_t)T * kB * 4), 0x00020000);
     const int col0 = 2 * first;
@@ -852,6 +912,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
             GAB_RT_STAMP_MAX(64, 0);
         }
     }
+    verify_and_rearm();                                          // (behind the hint: the host goes on to wait for the launch's END, which is behind this)
 }
 
 // The launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup walks them
@@ -1819,6 +1880,911 @@ __device__ __forceinline__ void conv_split_engine_resident(
     for (int i = tid; i < 2 * kCarrySlots * kB; i += kBatchThreads) carry_g[i] = carry[i];
 }
 
+// ---- n buffers per launch on TWELVE waves, three per SIMD (round 6) ----------------------------------------------------------
+// The batch launch above holds two waves per SIMD at 244 registers: a near wave and a far wave, and what the period costs
+// beyond the far role's own chain is what two waves cannot hide of each other's latency.  Here the far role is
+// TWO groups of four waves, group g owning pair g of the duo for the whole launch; a pair's turn comes every other buffer,
+// so a group takes TWO periods — twelve barrier intervals — per transform and each SIMD holds a near wave and a wave of
+// either group.  Same arithmetic on the same values in the same order as conv_split_batch_kernel (same transform passes,
+// same twiddle powers, same products, same sums): bit-identical to it and to n launches of conv_split_kernel.
+// What makes 168 registers per wave and 160 KB of LDS enough:
+//   * a group transforms in ONE padded LDS image (write, barrier, read, barrier: it has twelve intervals for six exchanges);
+//   * the carry ring goes through memory again (8 KB per pair and buffer, written and read within two periods by the same
+//     compute unit: L2 hits): its 32 KB of LDS hold the duo's NEAR spectra instead (taps [0,512) and [512,1024) of both
+//     pairs, 32.8 KB), loaded once per launch — the forward waves no longer carry 64 registers of spectra from one interval
+//     to the next, and no longer ask the L2 for 33 KB per duo and period;
+//   * the far waves keep the LAST pass's twiddle powers in registers (30) and read the middle pass's (16 distinct sets)
+//     from a 1.9 KB table in LDS, formed at entry by the same powers_of;
+//   * the A2 share waits in the hand-over image (written behind barrier 1, summed into behind barrier 5) instead of in
+//     32 registers; spectral products run in halves of eight bins.
+// The far role's schedule per transform (window nb, periods nb and nb + 1; the other group is one period out of step, so a
+// heavy interval of one meets a light one of the other):
+//   period nb:      pass 0 + write | read, pass 1 | write | read, pass 2 | partner write | partner read, product, inverse pass 0
+//   period nb + 1:  (next window's requests) | write | read, pass 1 | write | read, last pass (4 of 16), carry out | -
+constexpr int kB12Threads = 768;
+constexpr int kB12SpecCf = 4 * kBinsA * 2;                         // [A pair 0, A pair 1, A2 pair 0, A2 pair 1][513] float4, in cf entries
+constexpr int kB12Tw1Cf = 16 * 15;
+constexpr int kB12Lds = 6 * kWaveImg + 2 * kLdsHalf + kB12SpecCf + kB12Tw1Cf;     // cf entries (156 608 bytes)
+
+// bins [R0, R1) of load_spectra / spectral_product (same index rule, same operations per bin)
+template <int N, int R, int R0, int R1, class PM>
+__device__ __forceinline__ void load_spectra_part(float4 (&c)[R1 - R0], PM pm, int tid) {
+    constexpr int NT = N / R;
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        const int k = tid + r * NT;
+        if (r < R / 2) c[r - R0] = pm[k];
+        else if (r > R / 2) c[r - R0] = pm[N - k];
+        else c[r - R0] = pm[tid == 0 ? k : N - k];
+    }
+}
+template <int N, int R, int R0, int R1>
+__device__ __forceinline__ void spectral_product_part(cf (&z)[R], const cf (&zraw)[R1 - R0], const float4 (&c)[R1 - R0], int tid) {
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        cf P = mk(c[r - R0].x, c[r - R0].y), M = mk(c[r - R0].z, c[r - R0].w);
+        if (r > R / 2 || (r == R / 2 && tid != 0)) z[r] = fft::cfma_cjcj(zraw[r - R0], M, fft::cmulc(z[r], P));
+        else z[r] = fft::cfma_cj(zraw[r - R0], M, fft::cmul(z[r], P));
+    }
+}
+
+#ifdef GAB_ABLATE
+// diagnostic bit 64: in periods 32 and 33 of a launch every wave's lane 0 stamps s_memrealtime (100 MHz) when it ARRIVES at each of
+// the six barriers: slot = [block][wave (12)][period - 32][barrier]; tools/stamp_batch12.py
+#define GAB_B12BAR(period, i)                                                                                         \
+    do {                                                                                                              \
+        if (GAB_SDBG(64) && ((period) == 32 || (period) == 33) && lane == 0)                                          \
+            g_split_stamps[(((size_t)blockIdx.x * 12 + w) * 2 + ((period) - 32)) * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        __syncthreads();                                                                                              \
+    } while (0)
+#else
+#define GAB_B12BAR(period, i) __syncthreads()
+#endif
+__device__ __forceinline__ void conv_split_batch12_resident(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0, int n_buffers,
+    cf* __restrict__ lds) {
+    cf* const far_img = lds + 6 * kWaveImg;                           // [group][kLdsHalf]
+    float4* const spec = reinterpret_cast<float4*>(far_img + 2 * kLdsHalf);   // [A p0 | A p1 | A2 p0 | A2 p1][513]
+    cf* const tw1 = reinterpret_cast<cf*>(spec + 4 * kBinsA);          // [16][15]: W256^(r k), k = thread & 15 (the middle pass)
+    const int tid = threadIdx.x;
+    const int d = xcd_contiguous(blockIdx.x, gridDim.x);
+    const size_t step = (size_t)T * kB;
+    {
+        const float4* const gA = pmA + (size_t)(2 * d) * kBinsA;       // the duo's two pairs are contiguous
+        const float4* const gA2 = sp.pmA2 + (size_t)(2 * d) * kBinsA;
+        for (int i = tid; i < 2 * kBinsA; i += kB12Threads) { spec[i] = gA[i]; spec[2 * kBinsA + i] = gA2[i]; }
+        if (tid < 16) {
+            cf pw[15];
+            fft::powers_of<16>(tw[tid * (fft::kTwiddleN / 256)], pw);
+#pragma unroll
+            for (int r = 0; r < 15; ++r) tw1[tid * 15 + r] = pw[r];
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
+    auto idle_period = [&]() { for (int i = 0; i < kBatchBarriers; ++i) __syncthreads(); };
+
+    if (w >= 4) {
+        // ---- far waves: group g turns pair g of the duo, one transform per two periods
+        const int g = __builtin_amdgcn_readfirstlane((w - 4) >> 2);
+        const int ft = (tid - kThreads) & (kThreads - 1);
+#ifdef GAB_ABLATE
+        if (GAB_SDBG(2048)) __builtin_amdgcn_s_setprio(2);            // diagnostic builds: the far waves ahead of the near ones
+        if (GAB_SDBG(4096) && g == 1) __builtin_amdgcn_s_setprio(1);  // ... or only the younger group (the SIMD favours the older)
+#endif
+        cf* const img = far_img + g * kLdsHalf;
+        const int q = 2 * d + g;
+        const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const cg = sp.carry + (size_t)q * kCarrySlots * kB;
+        const size_t ca = (size_t)(2 * q) * kB, cb_ = ca + kB;
+        const float4* const pf = sp.pmF + (size_t)q * kBinsB;
+        using B16 = fft::Butterfly<16, false>;
+        using B16i = fft::Butterfly<16, true>;
+        cf tw2[15];                                                   // the last pass's powers: W4096^(r t)
+        fft::powers_of<16>(tw[ft], tw2);
+        // LDS positions are formed where they are used, from an opaque copy of the thread index: as loop invariants they
+        // would be kept (and spilled) across both halves of a transform
+        auto opaque_t = [&]() -> unsigned { unsigned v = (unsigned)ft; asm volatile("" : "+v"(v)); return v; };
+        auto w0_of = [](unsigned t) -> unsigned { return t * 17u; };                       // pass-0 writes: Pad(16 t + r) = 17 t + r
+        auto rd_of = [](unsigned t) -> unsigned { return t + (t >> 4); };                  // linear reads: Pad(t + 256 r) = rd + 272 r
+        auto w1_of = [](unsigned t) -> unsigned { const unsigned b1 = (t >> 4) * 256u + (t & 15u); return b1 + (b1 >> 4); };   // pass-1 writes: + 17 r
+        auto tw1row_of = [&](unsigned t) -> const cf* { return tw1 + (t & 15u) * 15u; };
+        // window of buffer nb: blocks k-7 .. k — from the input buffers where they lie inside the launch, else the ring
+        // PART 0: the seven older blocks' first halves + the newest block (16 requests); PART 1: the rest (16 requests) — the
+        // requests of one window go out in two intervals: thirty-two in one made that interval the period's longest
+        auto load_window = [&](auto part_tag, int nb, cf (&z)[16]) {
+            constexpr int PART = decltype(part_tag)::value;
+            const int head = (head0 + nb) & (kSlots - 1);
+            int fo = ft;
+            asm volatile("" : "+v"(fo));                              // (addresses formed here, not hoisted and spilled)
+            if constexpr (PART == 0) {
+                const float* const cur = in_slot(nb);
+                z[14] = mk(cur[ca + fo], cur[cb_ + fo]);
+                z[15] = mk(cur[ca + fo + kThreads], cur[cb_ + fo + kThreads]);
+            }
+            constexpr int BL0 = PART == 0 ? 4 : 0, BL1 = PART == 0 ? 7 : 4;       // blocks k-7+bl
+            if (nb >= kSlots - 1) {
+#pragma unroll
+                for (int bl = BL0; bl < BL1; ++bl) {
+                    const float* const src = in_slot(nb - (7 - bl));
+                    z[2 * bl] = mk(src[ca + fo], src[cb_ + fo]);
+                    z[2 * bl + 1] = mk(src[ca + fo + kThreads], src[cb_ + fo + kThreads]);
+                }
+            } else {
+#pragma unroll
+                for (int bl = BL0; bl < BL1; ++bl) {                  // block k-7+bl = buffer nb-7+bl (uniform branch)
+                    if (nb - 7 + bl >= 0) {
+                        const float* const src = in_slot(nb - (7 - bl));
+                        z[2 * bl] = mk(src[ca + fo], src[cb_ + fo]);
+                        z[2 * bl + 1] = mk(src[ca + fo + kThreads], src[cb_ + fo + kThreads]);
+                    } else {
+                        const int s = ((head + 1 + bl) & (kSlots - 1)) * kB;
+                        z[2 * bl] = hp[s + fo];
+                        z[2 * bl + 1] = hp[s + kThreads + fo];
+                    }
+                }
+            }
+        };
+        cf z[16], zn[16];
+        // The requests ride on the lighter steps (every instruction of a step costs the wave about a dozen clocks beside two
+        // others on its SIMD: thirty-two requests in one interval made it the period's longest), the wait for the carry's stores
+        // stands in the idle interval.  (Measured and not kept, profiles/r06_batch12_stamps.txt: steps cut as read + twiddle |
+        // butterfly + write, so that no step is a bare write — 5.08 against 5.01 us per buffer.)
+        // first half of a transform (period nb):   pass 0, write | read, twiddle, pass 1 | write (+ spectra 0-7) |
+        //                                          read, twiddle (+ spectra 8-15), pass 2 | partner write | partner read, product, inverse pass 0
+        auto first_half = [&](int nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = zn[r];
+            B16::run(z);
+            {
+                const unsigned w0 = w0_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w0 + r] = z[B16::out_slot(r)];
+            }
+            GAB_B12BAR(nb, 0);                                          // 1
+            {
+                const unsigned t = opaque_t(), rd = rd_of(t);
+                const cf* const tw1row = tw1row_of(t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw1row[r - 1]);
+            }
+            B16::run(z);
+            GAB_B12BAR(nb, 1);                                          // 2: every wave has read
+            {
+                const unsigned w1 = w1_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16::out_slot(r)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 clo[8], chi[8];                                    // the far spectra: bins r < 8 asked for here, r >= 8 an interval later
+            {
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_spectra_part<kNB, 16, 0, 8>(clo, pf, fo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_B12BAR(nb, 2);                                          // 3
+            {
+                const unsigned rd = rd_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+            }
+#pragma unroll
+            for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw2[r - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_spectra_part<kNB, 16, 8, 16>(chi, pf, fo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            B16::run(z);
+            GAB_B12BAR(nb, 3);                                          // 4
+            {
+                const unsigned t = opaque_t();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[t + 256u * r] = z[B16::out_slot(r)];   // Z[t + 256 r]: the partner exchange, raw
+            }
+            GAB_B12BAR(nb, 4);                                          // 5
+            {
+                // the thread's own bins back in order, and Z[(N - k) mod N], k = t + 256 r: one base and constant offsets for
+                // r >= 1 (N - k > 0 there); bin k = t alone wraps
+                cf o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = z[B16::out_slot(r)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = o[r];            // z[r] = Z[t + 256 r]
+                const unsigned t = opaque_t();
+                const cf* const pb = img + (kNB - 256 * 15) - t;      // pb[256 (15 - r)] = img[N - t - 256 r]
+                cf zp[8];
+                zp[0] = img[(kNB - t) & (kNB - 1)];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) zp[r] = pb[256 * (15 - r)];
+                spectral_product_part<kNB, 16, 0, 8>(z, zp, clo, ft);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = pb[256 * (7 - r)];
+                spectral_product_part<kNB, 16, 8, 16>(z, zp, chi, ft);
+            }
+            B16i::run(z);
+            GAB_B12BAR(nb, 5);                                          // 6
+        };
+        // second half (period nb + 1):   (half of the next window's requests) | write | read, twiddle, pass 1 |
+        //                                write (+ the other half) | read, twiddle, last pass (4 of 16), carry out | (the carry's stores leave)
+        auto second_half = [&](int period, int nb_done, int nb_next) {
+            if (nb_next >= 0) {
+                load_window(std::integral_constant<int, 0>{}, nb_next, zn);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = mk(0.0f, 0.0f);  // (no value survives from the last window: registers)
+            }
+            GAB_B12BAR(period, 0);                                          // 1
+            if (nb_done >= 0) {
+                const unsigned w0 = w0_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w0 + r] = z[B16i::out_slot(r)];
+            }
+            GAB_B12BAR(period, 1);                                          // 2
+            if (nb_done >= 0) {
+                const unsigned t = opaque_t(), rd = rd_of(t);
+                const cf* const tw1row = tw1row_of(t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw1row[r - 1]);
+                B16i::run(z);
+            }
+            GAB_B12BAR(period, 2);                                          // 3
+            if (nb_done >= 0) {
+                const unsigned w1 = w1_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16i::out_slot(r)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nb_next >= 0) load_window(std::integral_constant<int, 1>{}, nb_next, zn);      // the window's other half, beside the light write
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_B12BAR(period, 3);                                          // 4
+            if (nb_done >= 0) {
+                const unsigned rd = rd_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw2[r - 1]);
+                cf x12, x13, x14, x15;
+                B16i::run_last4(z, x12, x13, x14, x15);
+                const int head = (head0 + nb_done) & (kSlots - 1);
+                cf* const c1 = cg + ((head + 1) & (kCarrySlots - 1)) * kB;    // block k+1
+                cf* const c2 = cg + ((head + 2) & (kCarrySlots - 1)) * kB;    // block k+2
+                c1[ft] = x12;
+                c1[ft + kThreads] = x13;
+                c2[ft] = x14;
+                c2[ft + kThreads] = x15;
+            }
+            GAB_B12BAR(period, 4);                                          // 5
+            // the inverse wave of this pair asks for block k+1's share behind the period's closing barrier: the stores must
+            // have left this wave by then (waited for HERE, in the group's idle interval, not on its last pass)
+            if (nb_done >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GAB_B12BAR(period, 5);                                          // 6
+        };
+        const int first = (g - head0) & 1;                             // this group's first window
+        int nb = 0;
+        if (first == 1) {
+            second_half(0, -1, 1 < n_buffers ? 1 : -1);                   // period 0: nothing to finish, window 1 asked for
+            nb = 1;
+        } else if (n_buffers > 0) {
+            load_window(std::integral_constant<int, 0>{}, 0, zn);
+            load_window(std::integral_constant<int, 1>{}, 0, zn);
+        }
+        for (;;) {                                                     // nb: a period in which a transform of this group starts
+            if (nb > n_buffers) break;
+            if (nb < n_buffers) first_half(nb); else idle_period();
+            ++nb;
+            if (nb > n_buffers) break;
+            second_half(nb, nb - 1 < n_buffers ? nb - 1 : -1, nb + 1 < n_buffers ? nb + 1 : -1);
+            ++nb;
+        }
+    } else if (w < 2) {
+        // ---- forward waves: wave w holds pair w of the duo
+        const int q = 2 * d + w;
+        cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const img = lds + w * kWaveImg;                           // the transform's exchanges, then its spectrum
+        cf* const hand = lds + (2 + w) * kWaveImg;                    // A2 share, then the output spectrum for the inverse wave
+        const float4* const sa = spec + w * kBinsA;                   // taps [0,512)
+        const float4* const sa2 = spec + (2 + w) * kBinsA;            // taps [512,1024)
+        using WF = fft::WaveFFT1024<false>;
+        WF::Lean t;
+        WF::load_twiddles(t, tw, lane);
+        const size_t xoff = (size_t)(2 * q) * kB;                     // channel a of a buffer; channel b is kB further
+        cf z[16], prev[8], nxt[8];
+        // W = Z x spectra (from LDS) in halves of eight bins: partner values and spectra of a half live in registers at a time
+        auto product_from_image = [&](cf (&v)[16], const float4* sp_lds) {
+            {
+                cf zp[8];
+                float4 ch[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+                load_spectra_part<kNA, 16, 0, 8>(ch, sp_lds, lane);
+                spectral_product_part<kNA, 16, 0, 8>(v, zp, ch, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                cf zp[8];
+                float4 ch[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * (8 + r))) & (kNA - 1))];
+                load_spectra_part<kNA, 16, 8, 16>(ch, sp_lds, lane);
+                spectral_product_part<kNA, 16, 8, 16>(v, zp, ch, lane);
+            }
+        };
+        {   // prologue: the spectrum of the ring's blocks [k-2 | k-1] into the image
+            const int s1 = ((head0 + kSlots - 1) & (kSlots - 1)) * kB, s2 = ((head0 + kSlots - 2) & (kSlots - 1)) * kB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = hp[s1 + lane + 64 * j];
+            if (n_buffers > 0) {
+                const float* const x0 = in_slot(0) + xoff;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(x0[lane + 64 * j], x0[kB + lane + 64 * j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[8 + j] = prev[j];
+            WF::run(z, img, t, lane, WF::NoHook());
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int nb = 0; nb < n_buffers; ++nb) {
+            // A2 share | hand-over + window + pass 0 | pass 1 | pass 2 | spectrum + A product | sum into the hand-over
+            const int head = (head0 + nb) & (kSlots - 1);
+            {
+                cf share[16];                                         // taps [512,1024): last period's spectrum x its spectra
+#pragma unroll
+                for (int r = 0; r < 16; ++r) share[r] = img[rb + 68 * r];
+                product_from_image(share, sa2);
+                GAB_B12BAR(nb, 0);                                   // barrier 1: the inverse wave has read the hand-over image
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = share[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
+            if (nb + kSlots >= n_buffers) {                           // the ring only has to hold the launch's LAST eight blocks
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
+            if (nb + 1 < n_buffers) {                                 // the next buffer's block: needed a period from now
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = in_slot(nb + 1) + xoff + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(xa[64 * j], xa[kB + 64 * j]);
+            }
+            WF::run(z, img, t, lane, [&](int i) { GAB_B12BAR(nb, 1 + i); });   // barriers 2, 3 from inside
+            GAB_B12BAR(nb, 3);                                       // barrier 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];     // the spectrum stays here for the next period
+            __builtin_amdgcn_wave_barrier();
+            product_from_image(z, sa);
+            GAB_B12BAR(nb, 4);                                       // barrier 5
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = fft::cadd(z[r], hand[rb + 68 * r]);   // A product + A2 share
+            GAB_B12BAR(nb, 5);                                       // barrier 6 closes the period
+        }
+        idle_period();                                                // the pipeline's last period
+    } else {
+        // ---- inverse waves: wave 2 + p turns the output spectrum of pair p into samples, one period later
+        const int pr = w - 2;
+        const cf* const hand = lds + (2 + pr) * kWaveImg;
+        cf* const img = lds + (4 + pr) * kWaveImg;                    // the transform's exchanges, then the output swap
+        const cf* const other = lds + (4 + (1 - pr)) * kWaveImg;
+        const cf* const cg = sp.carry + (size_t)(2 * d + pr) * kCarrySlots * kB;
+        using WFi = fft::WaveFFT1024<true>;
+        WFi::Lean t;
+        WFi::load_twiddles(t, tw, lane);
+        idle_period();                                                // first period: nothing to turn yet
+        for (int nb = 1; nb <= n_buffers; ++nb) {
+            // hand-over read + far share asked for | pass 0 | pass 1 | pass 2 + far share | swap | stores
+            const int b = nb - 1;                                     // the buffer whose spectrum was handed over last period
+            const int head = (head0 + b) & (kSlots - 1);
+            float* const outb = out + (size_t)b * step;
+            cf z[16], y[8], park[8];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];
+            {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                // written by this workgroup's far waves one to three periods ago, behind barriers; agent-scope loads (answered
+                // by the L2, never by a line this compute unit's L1 kept from the slot's previous use four buffers ago)
+                const unsigned long long* const cy = reinterpret_cast<const unsigned long long*>(cg + (head & (kCarrySlots - 1)) * kB + lo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned long long v = __hip_atomic_load(cy + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    park[j] = mk(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+                }
+            }
+            GAB_B12BAR(nb, 0);                                       // barrier 1
+            WFi::run(z, img, t, lane, [&](int i) { GAB_B12BAR(nb, 1 + i); });  // barriers 2, 3 from inside
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+            GAB_B12BAR(nb, 3);                                       // barrier 4
+            if (pr == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[4 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
+            }
+            GAB_B12BAR(nb, 4);                                       // barrier 5: the swapped halves are in LDS
+            {
+                float* const o0 = outb + 4 * (size_t)d;
+                if (pr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const cf theirs = other[lane + 64 * j];
+                        *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * j)) = make_float4(y[j].x, y[j].y, theirs.x, theirs.y);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const cf theirs = other[lane + 64 * j];
+                        *reinterpret_cast<float4*>(o0 + (size_t)T * (lane + 64 * (4 + j))) = make_float4(theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                    }
+                }
+            }
+            GAB_B12BAR(nb, 5);                                       // barrier 6 closes the period
+        }
+    }
+}
+
+// ---- the same on SIX waves per workgroup, one pair each, two workgroups per compute unit (round 6) --------------------------------
+// Barrier timeline of the twelve-wave launch (tools/stamp_batch12.py, profiles/r06_batch12_stamps.txt): at EVERY barrier the last
+// wave to arrive is a far wave, the near waves wait half of the time, and each far group spends a third of its time waiting
+// for the OTHER group (an interval lasts as long as the slower of the two groups' steps, and the steps do not match).  The
+// two groups share nothing but the hardware barrier.  So each pair gets a workgroup of its own — a forward wave, an inverse
+// wave, four far waves; 79 KB of LDS, two workgroups per compute unit, still three waves per SIMD — and its own barrier.
+// What that gives up: the duo's output as 16-byte pieces (the inverse waves of two pairs swapping halves through LDS); a
+// pair stores its two channels as 8-byte pieces.  Same arithmetic: bit-identical.
+constexpr int kB6Threads = 6 * kWave;
+constexpr int kB6Lds = 3 * kWaveImg + kLdsHalf + 2 * kBinsA * 2 + kB12Tw1Cf;       // cf entries (79 232 bytes)
+
+#ifdef GAB_ABLATE
+#define GAB_PAIRBAR(period, i)                                                                                        \
+    do {                                                                                                              \
+        if (GAB_SDBG(64) && ((period) == 32 || (period) == 33) && lane == 0)                                          \
+            g_split_stamps[(((size_t)blockIdx.x * 12 + wave_id) * 2 + ((period) - 32)) * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        sync();                                                                                                       \
+    } while (0)
+#else
+#define GAB_PAIRBAR(period, i) sync()
+#endif
+// One pair's six waves (forward, inverse, four far).  `tid` = the thread's index among the pair's 384, `q` = the pair, `sync` = the
+// barrier the six waves meet at (the workgroup's hardware barrier where the workgroup IS the pair; a counter in LDS where two
+// pairs share a workgroup), `wave_id` = the wave's index in the workgroup (for the diagnostic stamps only).
+template <class Sync>
+__device__ __forceinline__ void conv_split_pair_resident(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0, int n_buffers,
+    cf* __restrict__ lds, const int tid, const int q, Sync& sync, const int wave_id) {
+    cf* const far_img = lds + 3 * kWaveImg;                           // [kLdsHalf]
+    float4* const spec = reinterpret_cast<float4*>(far_img + kLdsHalf);   // [A | A2][513]
+    cf* const tw1 = reinterpret_cast<cf*>(spec + 2 * kBinsA);          // [16][15]: W256^(r k), k = thread & 15 (the middle pass)
+    const size_t step = (size_t)T * kB;
+    {
+        const float4* const gA = pmA + (size_t)q * kBinsA;
+        const float4* const gA2 = sp.pmA2 + (size_t)q * kBinsA;
+        for (int i = tid; i < kBinsA; i += kB6Threads) { spec[i] = gA[i]; spec[kBinsA + i] = gA2[i]; }
+        if (tid < 16) {
+            cf pw[15];
+            fft::powers_of<16>(tw[tid * (fft::kTwiddleN / 256)], pw);
+#pragma unroll
+            for (int r = 0; r < 15; ++r) tw1[tid * 15 + r] = pw[r];
+        }
+    }
+    sync();
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
+    auto idle_period = [&]() { for (int i = 0; i < kBatchBarriers; ++i) sync(); };
+
+    if (w >= 2) {
+        // ---- far waves: the pair's transform, one per two periods (its turn comes every other buffer)
+        const int g = q & 1;                                          // the pair's turn: buffers whose ring slot has this parity
+        const int ft = tid - 2 * kWave;
+        cf* const img = far_img;
+        const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const cg = sp.carry + (size_t)q * kCarrySlots * kB;
+        const size_t ca = (size_t)(2 * q) * kB, cb_ = ca + kB;
+        const float4* const pf = sp.pmF + (size_t)q * kBinsB;
+        using B16 = fft::Butterfly<16, false>;
+        using B16i = fft::Butterfly<16, true>;
+        cf tw2[15];                                                   // the last pass's powers: W4096^(r t)
+        fft::powers_of<16>(tw[ft], tw2);
+        // LDS positions are formed where they are used, from an opaque copy of the thread index: as loop invariants they
+        // would be kept (and spilled) across both halves of a transform
+        auto opaque_t = [&]() -> unsigned { unsigned v = (unsigned)ft; asm volatile("" : "+v"(v)); return v; };
+        auto w0_of = [](unsigned t) -> unsigned { return t * 17u; };                       // pass-0 writes: Pad(16 t + r) = 17 t + r
+        auto rd_of = [](unsigned t) -> unsigned { return t + (t >> 4); };                  // linear reads: Pad(t + 256 r) = rd + 272 r
+        auto w1_of = [](unsigned t) -> unsigned { const unsigned b1 = (t >> 4) * 256u + (t & 15u); return b1 + (b1 >> 4); };   // pass-1 writes: + 17 r
+        auto tw1row_of = [&](unsigned t) -> const cf* { return tw1 + (t & 15u) * 15u; };
+        // window of buffer nb: blocks k-7 .. k — from the input buffers where they lie inside the launch, else the ring
+        auto load_window = [&](int nb, cf (&z)[16]) {
+            const int head = (head0 + nb) & (kSlots - 1);
+            int fo = ft;
+            asm volatile("" : "+v"(fo));                              // (addresses formed here, not hoisted and spilled)
+            const float* const cur = in_slot(nb);
+            z[14] = mk(cur[ca + fo], cur[cb_ + fo]);
+            z[15] = mk(cur[ca + fo + kThreads], cur[cb_ + fo + kThreads]);
+            if (nb >= kSlots - 1) {
+#pragma unroll
+                for (int bl = 0; bl < 7; ++bl) {
+                    const float* const src = in_slot(nb - (7 - bl));
+                    z[2 * bl] = mk(src[ca + fo], src[cb_ + fo]);
+                    z[2 * bl + 1] = mk(src[ca + fo + kThreads], src[cb_ + fo + kThreads]);
+                }
+            } else {
+#pragma unroll
+                for (int bl = 0; bl < 7; ++bl) {                      // block k-7+bl = buffer nb-7+bl (uniform branch)
+                    if (nb - 7 + bl >= 0) {
+                        const float* const src = in_slot(nb - (7 - bl));
+                        z[2 * bl] = mk(src[ca + fo], src[cb_ + fo]);
+                        z[2 * bl + 1] = mk(src[ca + fo + kThreads], src[cb_ + fo + kThreads]);
+                    } else {
+                        const int s = ((head + 1 + bl) & (kSlots - 1)) * kB;
+                        z[2 * bl] = hp[s + fo];
+                        z[2 * bl + 1] = hp[s + kThreads + fo];
+                    }
+                }
+            }
+        };
+        cf z[16], zn[16];
+        float4 c[16];
+        // first half of a transform: forward passes, partner exchange, product, first inverse butterfly (six barriers)
+        auto first_half = [&](int nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = zn[r];
+            B16::run(z);
+            {
+                const unsigned w0 = w0_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w0 + r] = z[B16::out_slot(r)];
+            }
+            GAB_PAIRBAR(nb, 0);                                          // 1
+            {
+                const unsigned t = opaque_t(), rd = rd_of(t);
+                const cf* const tw1row = tw1row_of(t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw1row[r - 1]);
+            }
+            B16::run(z);
+            GAB_PAIRBAR(nb, 1);                                          // 2: every wave has read
+            {
+                const unsigned w1 = w1_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16::out_slot(r)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_spectra<kNB, 16>(c, pf, fo);                     // needed three intervals from now
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_PAIRBAR(nb, 2);                                          // 3
+            {
+                const unsigned rd = rd_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+            }
+#pragma unroll
+            for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw2[r - 1]);
+            B16::run(z);
+            {
+                cf o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = z[B16::out_slot(r)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = o[r];            // z[r] = Z[t + 256 r]
+            }
+            GAB_PAIRBAR(nb, 3);                                          // 4
+            {
+                const unsigned t = opaque_t();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[t + 256u * r] = z[r];    // partner exchange, raw
+            }
+            GAB_PAIRBAR(nb, 4);                                          // 5
+            {
+                // Z[(N - k) mod N], k = t + 256 r: one base and constant offsets for r >= 1 (N - k > 0 there); bin k = t alone wraps
+                const unsigned t = opaque_t();
+                const cf* const pb = img + (kNB - 256 * 15) - t;      // pb[256 (15 - r)] = img[N - t - 256 r]
+                cf zp[8];
+                zp[0] = img[(kNB - t) & (kNB - 1)];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) zp[r] = pb[256 * (15 - r)];
+                float4 ch[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) ch[r] = c[r];
+                spectral_product_part<kNB, 16, 0, 8>(z, zp, ch, ft);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = pb[256 * (7 - r)];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) ch[r] = c[8 + r];
+                spectral_product_part<kNB, 16, 8, 16>(z, zp, ch, ft);
+            }
+            B16i::run(z);
+            GAB_PAIRBAR(nb, 5);                                          // 6
+        };
+        // second half: the inverse's exchanges and its last pass; the window of this group's NEXT transform is asked for
+        // in the first interval (the transform's own registers are busy until the last pass)
+        auto second_half = [&](int period, int nb_done, int nb_next) {
+            if (nb_next >= 0) {
+                load_window(nb_next, zn);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = mk(0.0f, 0.0f);  // (no value survives from the last window: registers)
+            }
+            GAB_PAIRBAR(period, 0);                                          // 1
+            if (nb_done >= 0) {
+                const unsigned w0 = w0_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w0 + r] = z[B16i::out_slot(r)];
+            }
+            GAB_PAIRBAR(period, 1);                                          // 2
+            if (nb_done >= 0) {
+                const unsigned t = opaque_t(), rd = rd_of(t);
+                const cf* const tw1row = tw1row_of(t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw1row[r - 1]);
+                B16i::run(z);
+            }
+            GAB_PAIRBAR(period, 2);                                          // 3
+            if (nb_done >= 0) {
+                const unsigned w1 = w1_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16i::out_slot(r)];
+            }
+            GAB_PAIRBAR(period, 3);                                          // 4
+            if (nb_done >= 0) {
+                const unsigned rd = rd_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw2[r - 1]);
+                cf x12, x13, x14, x15;
+                B16i::run_last4(z, x12, x13, x14, x15);
+                const int head = (head0 + nb_done) & (kSlots - 1);
+                cf* const c1 = cg + ((head + 1) & (kCarrySlots - 1)) * kB;    // block k+1
+                cf* const c2 = cg + ((head + 2) & (kCarrySlots - 1)) * kB;    // block k+2
+                c1[ft] = x12;
+                c1[ft + kThreads] = x13;
+                c2[ft] = x14;
+                c2[ft + kThreads] = x15;
+                // the inverse wave of this pair asks for block k+1's share behind the next closing barrier: the stores
+                // must have left this wave by then
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            GAB_PAIRBAR(period, 4);                                          // 5
+            GAB_PAIRBAR(period, 5);                                          // 6
+        };
+        const int first = (g - head0) & 1;                             // this group's first window
+        int nb = 0;
+        if (first == 1) {
+            second_half(0, -1, 1 < n_buffers ? 1 : -1);                   // period 0: nothing to finish, window 1 asked for
+            nb = 1;
+        } else if (n_buffers > 0) {
+            load_window(0, zn);
+        }
+        for (;;) {                                                     // nb: a period in which a transform of this group starts
+            if (nb > n_buffers) break;
+            if (nb < n_buffers) first_half(nb); else idle_period();
+            ++nb;
+            if (nb > n_buffers) break;
+            second_half(nb, nb - 1 < n_buffers ? nb - 1 : -1, nb + 1 < n_buffers ? nb + 1 : -1);
+            ++nb;
+        }
+    } else if (w == 0) {
+        // ---- the forward wave
+        cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const img = lds;                                          // the transform's exchanges, then its spectrum
+        cf* const hand = lds + kWaveImg;                              // A2 share, then the output spectrum for the inverse wave
+        const float4* const sa = spec;                                // taps [0,512)
+        const float4* const sa2 = spec + kBinsA;                      // taps [512,1024)
+        using WF = fft::WaveFFT1024<false>;
+        WF::Lean t;
+        WF::load_twiddles(t, tw, lane);
+        const size_t xoff = (size_t)(2 * q) * kB;                     // channel a of a buffer; channel b is kB further
+        cf z[16], prev[8], nxt[8];
+        // W = Z x spectra (from LDS) in halves of eight bins: partner values and spectra of a half live in registers at a time
+        auto product_from_image = [&](cf (&v)[16], const float4* sp_lds) {
+            auto quarter = [&](auto r0_tag) {
+                constexpr int R0 = decltype(r0_tag)::value;
+                cf zp[4];
+                float4 ch[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * (R0 + r))) & (kNA - 1))];
+                load_spectra_part<kNA, 16, R0, R0 + 4>(ch, sp_lds, lane);
+                spectral_product_part<kNA, 16, R0, R0 + 4>(v, zp, ch, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            quarter(std::integral_constant<int, 0>{});
+            quarter(std::integral_constant<int, 4>{});
+            quarter(std::integral_constant<int, 8>{});
+            quarter(std::integral_constant<int, 12>{});
+        };
+        {   // prologue: the spectrum of the ring's blocks [k-2 | k-1] into the image
+            const int s1 = ((head0 + kSlots - 1) & (kSlots - 1)) * kB, s2 = ((head0 + kSlots - 2) & (kSlots - 1)) * kB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = hp[s1 + lane + 64 * j];
+            if (n_buffers > 0) {
+                const float* const x0 = in_slot(0) + xoff;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(x0[lane + 64 * j], x0[kB + lane + 64 * j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[8 + j] = prev[j];
+            WF::run(z, img, t, lane, WF::NoHook());
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int nb = 0; nb < n_buffers; ++nb) {
+            // A2 share | hand-over + window + pass 0 | pass 1 | pass 2 | spectrum + A product | sum into the hand-over
+            const int head = (head0 + nb) & (kSlots - 1);
+            {
+                cf share[16];                                         // taps [512,1024): last period's spectrum x its spectra
+#pragma unroll
+                for (int r = 0; r < 16; ++r) share[r] = img[rb + 68 * r];
+                product_from_image(share, sa2);
+                GAB_PAIRBAR(nb, 0);                                   // barrier 1: the inverse wave has read the hand-over image
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = share[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
+            if (nb + kSlots >= n_buffers) {                           // the ring only has to hold the launch's LAST eight blocks
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
+            if (nb + 1 < n_buffers) {                                 // the next buffer's block: needed a period from now
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = in_slot(nb + 1) + xoff + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(xa[64 * j], xa[kB + 64 * j]);
+            }
+            WF::run(z, img, t, lane, [&](int i) { GAB_PAIRBAR(nb, 1 + i); });   // barriers 2, 3 from inside
+            GAB_PAIRBAR(nb, 3);                                       // barrier 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];     // the spectrum stays here for the next period
+            __builtin_amdgcn_wave_barrier();
+            product_from_image(z, sa);
+            GAB_PAIRBAR(nb, 4);                                       // barrier 5
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = fft::cadd(z[r], hand[rb + 68 * r]);   // A product + A2 share
+            GAB_PAIRBAR(nb, 5);                                       // barrier 6 closes the period
+        }
+        idle_period();                                                // the pipeline's last period
+    } else {
+        // ---- the inverse wave: turns the output spectrum into samples, one period later
+        const cf* const hand = lds + kWaveImg;
+        cf* const img = lds + 2 * kWaveImg;                           // the transform's exchanges
+        const cf* const cg = sp.carry + (size_t)q * kCarrySlots * kB;
+        using WFi = fft::WaveFFT1024<true>;
+        WFi::Lean t;
+        WFi::load_twiddles(t, tw, lane);
+        idle_period();                                                // first period: nothing to turn yet
+        for (int nb = 1; nb <= n_buffers; ++nb) {
+            // hand-over read + far share asked for | pass 0 | pass 1 | pass 2 + far share | - | stores
+            const int b = nb - 1;                                     // the buffer whose spectrum was handed over last period
+            const int head = (head0 + b) & (kSlots - 1);
+            float* const outb = out + (size_t)b * step;
+            cf z[16], y[8], park[8];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];
+            {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                // written by this workgroup's far waves one to three periods ago, behind barriers; agent-scope loads (answered
+                // by the L2, never by a line this compute unit's L1 kept from the slot's previous use four buffers ago)
+                const unsigned long long* const cy = reinterpret_cast<const unsigned long long*>(cg + (head & (kCarrySlots - 1)) * kB + lo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned long long v = __hip_atomic_load(cy + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    park[j] = mk(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+                }
+            }
+            GAB_PAIRBAR(nb, 0);                                       // barrier 1
+            WFi::run(z, img, t, lane, [&](int i) { GAB_PAIRBAR(nb, 1 + i); });  // barriers 2, 3 from inside
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+            GAB_PAIRBAR(nb, 3);                                       // barrier 4
+            {
+                float* const o0 = outb + 2 * (size_t)q;               // the pair's two channels: eight bytes per sample
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<float2*>(o0 + (size_t)T * (lane + 64 * j)) = make_float2(y[j].x, y[j].y);
+            }
+            GAB_PAIRBAR(nb, 4);                                       // barrier 5
+            GAB_PAIRBAR(nb, 5);                                       // barrier 6 closes the period
+        }
+    }
+}
+
+struct HardwareBarrier { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+// Six waves of a twelve-wave workgroup meet at a counter in LDS: lane 0 of each adds one (a release: the wave's LDS writes are
+// behind it in the LDS queue), every wave then reads the counter until all six of this round are in (an acquire).  Bounded:
+// a wave that is never joined goes on after about a second (the results are then wrong, the launch still ends).
+struct CounterBarrier {
+    unsigned* count;
+    unsigned target;
+    bool dead;                       // a wait has run out: no further waits (the launch ends at once, its results are wrong)
+    __device__ __forceinline__ void operator()() {
+        target += 6u;
+        if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dead) return;
+        for (int tries = 0;; ++tries) {
+            const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if ((int)(v - target) >= 0) break;
+            if (tries > (1 << 22)) { dead = true; break; }
+            __builtin_amdgcn_s_sleep(0);
+        }
+    }
+};
+
+__global__ __launch_bounds__(kB6Threads, 3) void conv_split_batch6_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
+    __shared__ __attribute__((aligned(16))) cf lds[kB6Lds];
+    HardwareBarrier sync;
+    // the pair: neighbours in one XCD, their output lines meet in its L2
+    conv_split_pair_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds, (int)threadIdx.x,
+                             xcd_contiguous(blockIdx.x, gridDim.x), sync, (int)(threadIdx.x >> 6));
+}
+
+// ---- two pairs per workgroup again, each with a barrier of its own (round 6) -------------------------------------------------------
+// conv_split_batch6_kernel runs a period in 3.43 us where ONE of its workgroups has a compute unit to itself (512 channels) —
+// but two never share one (a workgroup's six waves go to the SIMDs as 2, 2, 1, 1, and twice that is four waves of 166
+// registers on a SIMD: 1024 channels take two rounds, 6.9 us: profiles/r06_batch_forms.txt).  Here the two pairs of a duo are
+// again ONE workgroup of twelve waves — three per SIMD, 158 KB of LDS — but each pair's six waves meet at a counter in LDS
+// instead of the workgroup's hardware barrier, which all twelve would have to reach: nothing couples the two pairs.
+constexpr int kB26Threads = 2 * kB6Threads;
+__global__ __launch_bounds__(kB26Threads) void conv_split_batch2x6_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
+    __shared__ __attribute__((aligned(16))) cf lds[2 * kB6Lds];
+    __shared__ unsigned counters[2 * 32];                             // one per pair, a line apart
+    if (threadIdx.x < 2) counters[32 * threadIdx.x] = 0;
+    __syncthreads();
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) >= 6 ? 1 : 0);
+    CounterBarrier sync{counters + 32 * h, 0u, false};
+    conv_split_pair_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds + h * kB6Lds, (int)threadIdx.x - h * kB6Threads,
+                             2 * xcd_contiguous(blockIdx.x, gridDim.x) + h, sync, (int)(threadIdx.x >> 6));
+}
+
+__global__ __launch_bounds__(kB12Threads) void conv_split_batch12_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
+    __shared__ __attribute__((aligned(16))) cf lds[kB12Lds];         // (the spectra in it are read as 16-byte pieces)
+    conv_split_batch12_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds);
+}
+
 __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
@@ -2525,8 +3491,8 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     p->rt_groups = (int)fine.size();
     p->rt_bound[0] = 0;
     for (int g = 0; g < p->rt_groups; ++g) p->rt_bound[g + 1] = p->rt_bound[g] + (unsigned)fine[g];
-    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 1)));      // a 128-byte line per group
-    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 1)));
+    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 2)));      // a 128-byte line per group, one for the shares drained, one for the relayed `landed`
+    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 2)));
     GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
     for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
     GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
@@ -2604,10 +3570,26 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         // sentinel's fourth (round 5, caught by the self-classifying stress at 2052 channels: word 1 048 575, bytes 4 194 300 -
         // 4 194 303, consumed fff4b08e for bef4b08e; the r04 incident at 8192 channels has three such words:
         // profiles/r05_incident_torn_word.txt).  Within a packet the engine writes whole aligned bursts.
-        auto upload_pieces = [&]() {
-            for (size_t off = 0; off < bytes; off += gab::kRtUploadPiece)
+        long tear = -1;                                 // diagnostic builds: a word index whose early value is NOT the upload's (below)
+#ifdef GAB_ABLATE
+        if (getenv("GAB_RT_TEAR") && upload && mapped(h_in)) tear = atol(getenv("GAB_RT_TEAR"));
+        if (tear >= (long)(bytes / 4)) tear = -1;
+#endif
+        auto upload_range = [&](size_t lo, size_t hi) {
+            for (size_t off = lo; off < hi; off += gab::kRtUploadPiece)
                 GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->rt_stage) + off, reinterpret_cast<const char*>(h_in) + off,
-                                             std::min(gab::kRtUploadPiece, bytes - off), hipMemcpyHostToDevice, p->rt_copy_stream));
+                                             std::min(gab::kRtUploadPiece, hi - off), hipMemcpyHostToDevice, p->rt_copy_stream));
+        };
+        auto upload_pieces = [&]() {
+            if (tear < 0) { upload_range(0, bytes); return; }
+            // Diagnostic builds, GAB_RT_TEAR=<word>: what a torn or reordered engine write would look like to the kernel.  The word is
+            // in the staging buffer with ONE BIT WRONG before the launch (the kernel takes it the moment its neighbours land), the
+            // upload leaves it out, and the right value goes up only when the rest is through, just before `landed` is released:
+            // the consumed word differs from what the completed upload left, and the call must say so.
+            unsigned wrong = reinterpret_cast<const unsigned*>(h_in)[tear] ^ 0x00010000u;
+            GAB_HIP_CHECK(hipMemcpy(p->rt_stage + tear, &wrong, 4, hipMemcpyHostToDevice));
+            upload_range(0, (size_t)tear * 4);
+            upload_range((size_t)tear * 4 + 4, bytes);
         };
         if (upload && !mapped(h_in)) {
             upload_pieces();
@@ -2618,7 +3600,7 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             upload_pieces();
         }
         gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
-                              epoch, p->rt_groups, {}};
+                              p->rt_counters + 32 * (p->rt_groups + 1), epoch, p->rt_groups, {}};
         for (int g = 0; g <= p->rt_groups; ++g) rt.bound[g] = p->rt_bound[g];
         if (completion == 2)
             hipExtLaunchKernelGGL(gab::conv_round_trip_kernel, dim3(p->pairs), dim3(gab::kThreads), 0, s, nullptr, p->rt_done_ev, 0,
@@ -2656,7 +3638,14 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         unsigned spins = 0;
         bool ended = false;
         while (!told || *done != epoch) {
-            if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) { __atomic_store_n(landed, epoch, __ATOMIC_RELEASE); told = true; }
+            if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) {
+                if (tear >= 0) {                            // (diagnostic builds) the word's right value, late
+                    GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage + tear, reinterpret_cast<const unsigned*>(h_in) + tear, 4, hipMemcpyHostToDevice, p->rt_copy_stream));
+                    GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
+                }
+                __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);
+                told = true;
+            }
             if ((++spins & 1023u) == 0) {
                 if (told && hipStreamQuery(s) == hipSuccess) { ended = true; break; }      // over without the hint: a wait ran out
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0)
@@ -2676,6 +3665,9 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
                     return after_a_failed_wait("the launch did not end within 4 s");
             }
         }
+        if (*error & gab::kRtErrTorn)
+            return after_a_failed_wait("a word the kernel consumed while the upload was still running is not the word the completed upload left in "
+                                       "the staging buffer (an engine write that landed in pieces or out of order)");
         if (*error != 0) return after_a_failed_wait("a workgroup waited about a second for its input and gave up");
         if (*done != epoch) return after_a_failed_wait("the launch ended without draining every channel group");
         if (p->warm_on) (void)gab_keep_warm_kick(p->warm);       // the result is out: keep the device from going idle until the next slot
@@ -3027,10 +4019,29 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
                 const int n = (int)std::min<size_t>(chunk_max, (size_t)(n_buffers - done));
                 int rc;
                 if (p->split) {
-                    // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches
-                    gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
-                        d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
-                    rc = gab::launch_status("conv_split_batch_kernel");
+                    // the split cut, both roles of a duo in one resident workgroup: same bits as n split launches.
+                    // Twelve waves (three per SIMD, round 6) or eight (two per SIMD): same bits either way
+                    int waves = gab::kBatchWaves;
+#ifdef GAB_ABLATE
+                    if (getenv("GAB_BATCH_WAVES")) waves = atoi(getenv("GAB_BATCH_WAVES"));     // diagnostic builds: A/B on one box
+#endif
+                    if (waves == 26) {
+                        gab::conv_split_batch2x6_kernel<<<dim3(p->tracks / 4), dim3(gab::kB26Threads), 0, s>>>(
+                            d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
+                        rc = gab::launch_status("conv_split_batch2x6_kernel");
+                    } else if (waves == 6) {
+                        gab::conv_split_batch6_kernel<<<dim3(p->tracks / 2), dim3(gab::kB6Threads), 0, s>>>(
+                            d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
+                        rc = gab::launch_status("conv_split_batch6_kernel");
+                    } else if (waves == 12) {
+                        gab::conv_split_batch12_kernel<<<dim3(p->tracks / 4), dim3(gab::kB12Threads), 0, s>>>(
+                            d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
+                        rc = gab::launch_status("conv_split_batch12_kernel");
+                    } else {
+                        gab::conv_split_batch_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
+                            d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
+                        rc = gab::launch_status("conv_split_batch_kernel");
+                    }
                 } else {
                     gab::conv_batch_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(
                         d_in + done * step, d_out + done * step, p->hist, p->pmA, p->pmB, p->tw, p->tracks, p->head, n);

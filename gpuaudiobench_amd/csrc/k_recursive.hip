@@ -836,6 +836,119 @@ __global__ __launch_bounds__(256) void dwg_cells_append_kernel(const WG* __restr
     }
 }
 
+// ---- round 6: the same cells, a quarter of the instructions ---------------------------------------------------------
+// Counters of the kernel above at 8192 lines (profiles/r06_dwg_pmc.md): 523 vector and 417 scalar instructions per WAVE for
+// 16 loads, 16 stores and 80 floating-point operations — 64-bit pointer arithmetic per cell, an exec-mask region per
+// `if (live)` per loop, a divide in the tap bookkeeping — and a wave alive 4 650 issue slots of which it issues in 1 100:
+// the launch is bound by instruction issue (the scalar unit is one per compute unit: 13 000 scalar instructions each), not
+// by its 61 MB.  Here:
+//   * the delay lines are BUFFER resources: a cell's address is one v_lshl_add (line base + 4 p, 32 bits), and a lane that
+//     owns no cell of a line carries the offset 0xffffffff — its load returns zero and its store is dropped by the
+//     resource's range check, so no exec-mask region is needed around either;
+//   * wrap-arounds as min(p, p - L) on unsigned values (two instructions);
+//   * lines of B cells and more (four in five of the reference's 100..1999) take ONE step per lane: straight-line code, the
+//     loop over further samples behind a scalar branch on L < B;
+//   * the output tap (at most one lane per line) is remembered as a bit and a value and handled for all U lines in one
+//     region after the stores, which most waves skip.
+// Same floating-point operations per cell in the same order (the injection stays a select: f + 0 is not f for f = -0):
+// bit-identical to the forms above (test_dwg_large_bank_*).
+template <int U>
+__global__ __launch_bounds__(256) void dwg_cells_lean_kernel(const WG* __restrict__ wgs,
+                                                            float* __restrict__ fwd, float* __restrict__ bwd,
+                                                            const float* __restrict__ input,
+                                                            float* __restrict__ ws, int2* __restrict__ hits,
+                                                            int2* __restrict__ mix_list, int n_wg, int n_mix, int B,
+                                                            int max_len, int slot, unsigned line_bytes_total) {
+    int* const count = g_dwg_count[slot];
+    const int g0 = blockIdx.y * U;
+    const unsigned s0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const auto rf = __builtin_amdgcn_make_buffer_rsrc(fwd, 0, (int)line_bytes_total, 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(bwd, 0, (int)line_bytes_total, 0x00020000);
+    const float x0 = s0 < (unsigned)B ? input[s0] : 0.0f;
+    // all U records requested at once, nothing conditional between them (a line beyond the bank re-reads the last record
+    // and owns no cell below): one wait for the scalar loads instead of one per line
+    WG wg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wg[u] = wgs[min(g0 + u, n_wg - 1)];
+    if (blockIdx.x == 0 && threadIdx.x < U && g0 + (int)threadIdx.x < n_wg)      // lane u of the first wave: where line u's tap is reached
+        dwg_publish_hits(wgs[g0 + threadIdx.x], g0 + threadIdx.x, hits);
+    unsigned of[U], ob[U];                                     // byte offsets of this lane's two cells; 0xffffffff: none
+    unsigned cell[U];
+    unsigned livebits = 0;                                     // bit u: this lane owns a cell of line u
+    float f[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int g = g0 + u;
+        const unsigned L = (unsigned)wg[u].length;
+        const unsigned wp = (unsigned)wrap_once(wg[u].writePos, wg[u].length);
+        const unsigned lim = g < n_wg ? (L < (unsigned)B ? L : (unsigned)B) : 0u;   // the buffer visits min(L, B) cells of the line
+        unsigned p = wp + s0;
+        p = min(p, p - L);                                      // both addends below L (live lanes): one wrap
+        unsigned q = p + (L >> 1);
+        q = min(q, q - L);
+        const unsigned base = (unsigned)g * (unsigned)max_len * 4u;
+        const bool live = s0 < lim;
+        of[u] = live ? base + 4u * p : 0xffffffffu;
+        ob[u] = live ? base + 4u * q : 0xffffffffu;
+        cell[u] = p;
+        livebits |= live ? (1u << u) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        f[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, of[u], 0, 0));
+        b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, ob[u], 0, 0));
+    }
+    unsigned tapbits = 0;
+    float tapval[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool live = (livebits >> u) & 1u;
+        const bool inject = cell[u] == (unsigned)wg[u].inTap;                 // (a lane without a cell: its values go nowhere)
+        const bool tap = live && cell[u] == (unsigned)wg[u].outTap;
+        float mix;
+        dwg_step(f[u], b[u], __fmul_rn(x0, wg[u].gain), inject, wg[u], mix);
+        tapval[u] = mix;
+        tapbits |= tap ? (1u << u) : 0u;
+        if (wg[u].length < B) {                                 // (uniform) a short line: this lane's cell is visited again
+            const int g = g0 + u;
+            if (tap && g < n_mix) {                             // the first visit's tap value goes out here: the loop overwrites it
+                ws[(size_t)g * B + s0] = mix;
+                const int idx = atomicAdd(&count[s0], 1);
+                if (idx < kMixCap) mix_list[(size_t)s0 * kMixCap + idx] = make_int2(g, __float_as_int(mix));
+            } else if (tap) {
+                ws[(size_t)g * B + s0] = mix;
+            }
+            tapbits &= ~(1u << u);
+            if (live) {
+                for (unsigned s = s0 + (unsigned)wg[u].length; s < (unsigned)B; s += (unsigned)wg[u].length) {
+                    dwg_step(f[u], b[u], __fmul_rn(input[s], wg[u].gain), inject, wg[u], mix);
+                    if (tap) {
+                        ws[(size_t)g * B + s] = mix;
+                        if (g < n_mix) {
+                            const int idx = atomicAdd(&count[s], 1);
+                            if (idx < kMixCap) mix_list[(size_t)s * kMixCap + idx] = make_int2(g, __float_as_int(mix));
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f[u]), rf, of[u], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b[u]), rb, ob[u], 0, 0);
+    }
+    if (tapbits) {                                              // at most one lane per line: most waves skip this
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!((tapbits >> u) & 1u)) continue;
+            const int g = g0 + u;
+            ws[(size_t)g * B + s0] = tapval[u];                 // (the crowded-sample scan's copy)
+            if (g < n_mix) {
+                const int idx = atomicAdd(&count[s0], 1);
+                if (idx < kMixCap) mix_list[(size_t)s0 * kMixCap + idx] = make_int2(g, __float_as_int(tapval[u]));
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace gab
 
@@ -955,7 +1068,9 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                 static Slot slots[gab::kDwgSlots];
                 static std::mutex slots_mu;
                 static unsigned next_slot = 0;
-                int form = 2;                                    // 0: round 5's (U = 8, staged input); 1: U = 8; 2: U = 16
+                // 0: round 5's (8 lines per workgroup, staged input)   1, 2: no staging, 8 / 16 lines (r06: no faster — it was
+                // never the staging)   3, 4: the lean kernel, 8 / 16 lines (delay lines of 4 GiB and more per array: form 0)
+                int form = 3;
 #ifdef GAB_ABLATE
                 if (getenv("GAB_DWG_FORM")) form = atoi(getenv("GAB_DWG_FORM"));     // diagnostic builds: A/B on one box
 #endif
@@ -966,13 +1081,21 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                 Slot& sl = slots[slot];
                 if (!sl.busy) GAB_HIP_CHECK(hipEventCreateWithFlags(&sl.busy, hipEventDisableTiming));
                 if (sl.used && sl.last != s) GAB_HIP_CHECK(hipStreamWaitEvent(s, sl.busy, 0));
-                const int UU = form == 2 ? 16 : U;
+                const unsigned long long line_bytes = 4ull * (unsigned long long)n_waveguides * (unsigned long long)max_len;
+                if (line_bytes >= 0xffffff00ull && form >= 3) form = 0;      // (a buffer resource's range is 32 bits)
+                const int UU = (form == 2 || form == 4) ? 16 : form == 5 ? 4 : U;
                 dim3 grid((cells + 255) / 256, (n_waveguides + UU - 1) / UU);
 #define GAB_DWG_APPEND(UV, ST) gab::dwg_cells_append_kernel<UV, ST><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, \
                                                                                 n_waveguides, n_mix, bufsize, max_len, slot)
-                if (form == 2) GAB_DWG_APPEND(16, false);
+#define GAB_DWG_LEAN(UV) gab::dwg_cells_lean_kernel<UV><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, n_waveguides, n_mix, \
+                                                                      bufsize, max_len, slot, (unsigned)line_bytes)
+                if (form == 5) GAB_DWG_LEAN(4);
+                else if (form == 4) GAB_DWG_LEAN(16);
+                else if (form == 3) GAB_DWG_LEAN(U);
+                else if (form == 2) GAB_DWG_APPEND(16, false);
                 else if (form == 1) GAB_DWG_APPEND(U, false);
                 else GAB_DWG_APPEND(U, true);
+#undef GAB_DWG_LEAN
 #undef GAB_DWG_APPEND
                 int rc = gab::launch_status("dwg_cells_append_kernel");
                 if (rc) return rc;                               // (nothing was appended: the slot is still zero)

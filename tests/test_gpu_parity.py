@@ -551,6 +551,23 @@ def test_keep_warm_launch_comes_and_goes_and_changes_no_bits(gab, orc):
         gab.KeepWarm(workgroups=8, idle_seconds=0.0)
 
 
+def test_conv_accel_round_trip_reports_a_word_consumed_with_the_wrong_value(gab, orc):
+    """The overlapped round trip takes input words while the upload is still running; that rests on engine writes landing
+    whole and once (an observation: profiles/r05_incident_torn_word.txt was a violation nobody reported).  Since round 6 the
+    consumed words are compared with what the COMPLETED upload left, before the launch ends: a diagnostic build that shows
+    the kernel one wrong bit early (GAB_RT_TEAR; three word positions) must fail AT THAT CALL with GAB_ERR_RUNTIME and be
+    right again after a reset (tools/round_trip_tear_check.py, a child process: the variable is read by the library)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gpuaudiobench_amd", "libgab_hip_ablate.so")
+    if not os.path.exists(lib):
+        pytest.skip("no diagnostic build")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "round_trip_tear_check.py")], cwd=root,
+                       env=dict(os.environ, GAB_LIB_PATH=lib), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert r.stdout.count("failed at that call") == 3 and "bit for bit: ok" in r.stdout, r.stdout
+
+
 def test_conv_accel_round_trip_input_that_holds_the_sentinel(gab, orc):
     """A buffer that really contains the staging sentinel (a NaN no audio carries) is released by the upload's
     completion instead of by the words changing: slower, same bits as the device-buffer launch (NaNs and all)."""
