@@ -7,7 +7,7 @@
 A "step" is one pass of the hot path over the resident batch of synthetic input:
 BUFFERS_PER_STEP = 128 consecutive audio buffers (512 new samples for every one of a
 rank's 1024 channels) pushed through overlap-save with carried history by ONE launch
-of gab_conv_process_batch (conv_split_batch_kernel: a workgroup owns four channels for
+of gab_conv_process_batch (conv_split_batch12_kernel: a workgroup of twelve waves owns four channels for
 the whole launch and walks the 128 buffers in order).  The inputs are resident in HBM
 before the timed region starts — the precondition the metric is quoted under — so
 nothing has to cross a kernel boundary between buffers; history carries over from one
@@ -54,7 +54,7 @@ CLOCK_WARM_STEPS = 500          # untimed, besides --warmup: ~0.2 s of the same 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 PARITY_CHANNELS = 16            # sampled per checked buffer
 PARITY_TOL = 1e-5               # of the stream's peak (north_star: 1e-5 relative for float DSP)
-TRAFFIC_SOURCE = "profiles/r05_conv_batch_pmc_means.json"
+TRAFFIC_SOURCE = "profiles/r06_conv_batch_pmc_means.json"
 
 
 def cpu_threads():
@@ -335,9 +335,9 @@ def main():
             # `bound` names the roofline the contract prices against (algorithmic bytes over the 8 TB/s HBM peak);
             # what actually limits the kernel is `limited_by` / `bound_measured`: not memory
             "bound": "hbm",
-            "limited_by": "instruction issue and latency of the far role's transform chain (one wave per SIMD beside a near wave), not HBM: "
-                          "see bound_measured and hbm_frac_measured",
-            "kernel": "conv_split_batch_kernel",
+            "limited_by": "instruction issue and barrier waits of the far role's transform chains (two four-wave groups, three waves per SIMD; "
+                          "every barrier's last arrival is a far wave: profiles/r06_batch12_stamps.txt), not HBM: see bound_measured and hbm_frac_measured",
+            "kernel": "conv_split_batch12_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -348,7 +348,7 @@ def main():
             # every tap and every history sample a 4096-tap FIR depends on), most of which this kernel keeps in LDS, registers
             # and the Infinity Cache, so frac is a rate of useful work, not HBM utilisation
             "hbm_frac_measured": (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic is not None and NB == BUFFERS_PER_STEP else None,
-            "bound_measured": ("barriers and latency of two resident waves per SIMD: VALU busy %.0f %% of wave-cycles, HBM-side traffic %.2f x "
+            "bound_measured": ("barriers and latency of three resident waves per SIMD: VALU busy %.0f %% of wave-cycles, HBM-side traffic %.2f x "
                                "algorithmic (counters of %s)" % (100 * valu_share, traffic / (alg * BUFFERS_PER_STEP), TRAFFIC_SOURCE))
                               if traffic is not None and valu_share is not None else None,
             "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over the same "
@@ -359,7 +359,7 @@ def main():
             "launch_us": launch_us,
             "how": "achieved = algorithmic bytes per launch (%d buffers x 4*T*(2B+2L)) / average launch period "
                    "(two HIP events on the launch stream around the %d timed launches); rocprofv3's average "
-                   "duration of conv_split_batch_kernel is the same quantity" % (NB, args.steps),
+                   "duration of conv_split_batch12_kernel is the same quantity" % (NB, args.steps),
         },
         "parity_checked": parity,
     }
@@ -471,7 +471,7 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     ahead, passes = 16, 64
     # The engine's ring is HALF a step (64 slots: 128 MiB in, 128 MiB out), and every batch launch of this leg — the clock
     # warm-up, the reference — is a launch of a whole step's size over the ring's contents twice: rocprofv3's per-kernel
-    # average of the command then averages launches of ONE size (conv_split_batch_kernel: `value`'s).
+    # average of the command then averages launches of ONE size (conv_split_batch12_kernel: `value`'s).
     NB_step, NB = NB, (NB // 2 if NB // 2 > ahead else NB)
     xb_step, xb = xb, xb[:NB * T * B]
     per = NB_step // NB                                # ring passes per reference launch (2, or 1 for a small step)

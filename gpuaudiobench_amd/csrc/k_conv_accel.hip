@@ -2344,6 +2344,7 @@ __device__ __forceinline__ void conv_split_batch12_resident(
     }
 }
 
+#ifdef GAB_ABLATE      // diagnostic builds only (GAB_BATCH_WAVES = 6 / 26): two forms that were measured and not kept
 // ---- the same on SIX waves per workgroup, one pair each, two workgroups per compute unit (round 6) --------------------------------
 // Barrier timeline of the twelve-wave launch (tools/stamp_batch12.py, profiles/r06_batch12_stamps.txt): at EVERY barrier the last
 // wave to arrive is a far wave, the near waves wait half of the time, and each far group spends a third of its time waiting
@@ -2777,6 +2778,8 @@ __global__ __launch_bounds__(kB26Threads) void conv_split_batch2x6_kernel(
     conv_split_pair_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds + h * kB6Lds, (int)threadIdx.x - h * kB6Threads,
                              2 * xcd_contiguous(blockIdx.x, gridDim.x) + h, sync, (int)(threadIdx.x >> 6));
 }
+
+#endif   // GAB_ABLATE
 
 __global__ __launch_bounds__(kB12Threads) void conv_split_batch12_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
@@ -4025,6 +4028,7 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
 #ifdef GAB_ABLATE
                     if (getenv("GAB_BATCH_WAVES")) waves = atoi(getenv("GAB_BATCH_WAVES"));     // diagnostic builds: A/B on one box
 #endif
+#ifdef GAB_ABLATE
                     if (waves == 26) {
                         gab::conv_split_batch2x6_kernel<<<dim3(p->tracks / 4), dim3(gab::kB26Threads), 0, s>>>(
                             d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
@@ -4033,7 +4037,10 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
                         gab::conv_split_batch6_kernel<<<dim3(p->tracks / 2), dim3(gab::kB6Threads), 0, s>>>(
                             d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
                         rc = gab::launch_status("conv_split_batch6_kernel");
-                    } else if (waves == 12) {
+                    } else
+#endif
+                    if (waves == 12) {
+
                         gab::conv_split_batch12_kernel<<<dim3(p->tracks / 4), dim3(gab::kB12Threads), 0, s>>>(
                             d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
                         rc = gab::launch_status("conv_split_batch12_kernel");
