@@ -82,6 +82,7 @@ PROTOTYPES = {
     "gab_link_plan_create": (_I, [_I, C.POINTER(_P)]),
     "gab_link_plan_destroy": (None, [_P]),
     "gab_datatransfer_round_trip": (_I, [_P, _P, _P, _I, _I, _P]),
+    "gab_datatransfer_round_trip_check": (_I, [_P]),
     "gab_keep_warm_create": (_I, [C.POINTER(_P), _I, C.c_double]),
     "gab_keep_warm_kick": (_I, [_P]),
     "gab_keep_warm_running": (_I, [_P, C.POINTER(_I)]),
@@ -107,6 +108,8 @@ PROTOTYPES = {
     "gab_conv_get_scheme": (_I, [_P, C.POINTER(_I)]),
     "gab_conv_process_batch": (_I, [_P, _P, _P, _I, _P]),
     "gab_conv_round_trip": (_I, [_P, _P, _P, _P]),
+    "gab_conv_round_trip_check": (_I, [_P]),
+    "gab_conv_round_trip_set_check": (_I, [_P, _I]),
     "gab_conv_newest_block": (_I, [_P, _P, _P]),
     "gab_conv_round_trip_keep_warm": (_I, [_P, _I]),
     "gab_conv_round_trip_keep_warm_placement": (_I, [_P, _P, _P, _I, C.POINTER(_I)]),

@@ -170,7 +170,6 @@ struct LinkRoundTrip {
     const unsigned* landed;       // pinned host: the epoch, once the host has seen the upload complete
     unsigned* error;              // pinned host: bit 0 a wait ran out, bit 1 a consumed word is not what the completed upload left
     unsigned* consumed;           // device: [>= in_size] the words as the kernel took them, until they have been checked
-    unsigned* relay;              // device: `landed` as workgroup 0 last saw it
     unsigned epoch;
     int in_size, out_size;
 };
@@ -187,10 +186,9 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
     const int chunks = (rt.out_size + kLinkChunk - 1) / kLinkChunk;
     const int dep_chunks = (dep + kLinkChunk - 1) / kLinkChunk;      // chunks that hold at least one input word
     const int free_chunks = chunks - dep_chunks;
-    bool gave_up = false, took = false;
+    bool gave_up = false;
     for (int pos = blockIdx.x; pos < chunks; pos += gridDim.x) {
         const int chunk = pos < free_chunks ? dep_chunks + pos : pos - free_chunks;
-        took = took || chunk < dep_chunks;                            // (uniform over the workgroup)
         const int w0 = chunk * kLinkChunk + 4 * tid;                  // this thread's four words
         const int n_in = max(0, min(4, dep - w0));                    // how many of them are input words
         unsigned w[4] = {0, 0, 0, 0};
@@ -254,41 +252,20 @@ __global__ __launch_bounds__(kBlock) void datatransfer_round_trip_kernel(LinkRou
         const unsigned old = __hip_atomic_fetch_add(rt.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == rt.epoch * gridDim.x) __hip_atomic_store(rt.done, rt.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // ---- round 6: what was consumed EARLY against what the COMPLETED upload left (k_conv_accel.hip, rt_landed: the hand-off
-    // rests on engine writes landing whole and once — an observation; a violation must not be silent).  Behind the acquire of
-    // the host's `landed` (workgroup 0's first wave asks the host and passes it on, the others ask the relay) every input
-    // word this workgroup took is read again and compared with the copy it kept; only then does the sentinel go back.
-    // The outputs have left and the hint word is out: this runs beside the last workgroups' rows, before the launch's end.
-    const bool ask_host = blockIdx.x == 0 && tid < kWave;
-    if (!gave_up && dep_chunks > 0 && (took || blockIdx.x == 0)) {   // (workgroup 0 passes the word on whether it took input or not)
-        int tries = 0;
-        for (;;) {
-            bool in_ = false;
-            if (ask_host) {
-                const unsigned h = __hip_atomic_load(rt.landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (h == rt.epoch) { __hip_atomic_store(rt.relay, h, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); in_ = true; }
-            } else {
-                in_ = __hip_atomic_load(rt.relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == rt.epoch;
-            }
-            if (in_) break;
-            if (++tries > kLinkPollLimit) { gave_up = true; break; }
-            if (ask_host) __builtin_amdgcn_s_sleep(30); else __builtin_amdgcn_s_sleep(10);
-        }
-        if (gave_up) __hip_atomic_store(rt.error, kLinkErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+}
+
+// Round 6 (see k_conv_accel.hip, conv_round_trip_check_kernel): the words the kernel above took while the upload was still
+// running — it keeps a copy in `consumed` and leaves the staging buffer as it is — against what the COMPLETED upload left: a
+// second launch behind it, ordered behind the upload's completion event, compares and puts the sentinel back.  Its verdict is
+// read by the plan's next call or by gab_datatransfer_round_trip_check.
+__global__ __launch_bounds__(kBlock) void datatransfer_round_trip_check_kernel(unsigned* __restrict__ stage, const unsigned* __restrict__ consumed,
+                                                                              unsigned* __restrict__ verdict, int dep) {
     bool torn = false;
-    for (int pos = blockIdx.x; pos < chunks; pos += gridDim.x) {
-        const int chunk = pos < free_chunks ? dep_chunks + pos : pos - free_chunks;
-        if (chunk >= dep_chunks) continue;
-        const int w0 = chunk * kLinkChunk + 4 * tid;
-        const int n_in = max(0, min(4, dep - w0));
-        for (int k = 0; k < 4; ++k) {
-            if (k >= n_in) continue;
-            if (!gave_up) torn = torn || link_peek(rt.stage + w0 + k) != rt.consumed[w0 + k];
-            __hip_atomic_store(rt.stage + w0 + k, kLinkSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the sentinel goes back for the next call
-        }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < dep; i += gridDim.x * kBlock) {
+        torn = torn || link_peek(stage + i) != consumed[i];
+        __hip_atomic_store(stage + i, kLinkSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (torn) __hip_atomic_fetch_or(rt.error, kLinkErrTorn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (torn) __hip_atomic_fetch_or(verdict, kLinkErrTorn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- modal (placeholder semantics) ---------------------------------------------
@@ -459,8 +436,11 @@ struct gab_link_plan {
     // data, not the sentinel, and a later call that reads them must find the sentinel first
     int stale_lo = 0, stale_hi = 0;
     unsigned* consumed = nullptr;       // device: the words as the kernel took them (checked against the completed upload)
+    hipEvent_t check_ev = nullptr;      // behind datatransfer_round_trip_check_kernel (words[48]: its verdict)
+    bool check_pending = false;
     ~gab_link_plan() {
         if (consumed) (void)hipFree(consumed);
+        if (check_ev) (void)hipEventDestroy(check_ev);
         if (stage) (void)hipFree(stage);
         if (counter) (void)hipFree(counter);
         if (words) (void)hipHostFree(words);
@@ -481,8 +461,9 @@ int gab_link_plan_create(int max_in_size, gab_link_plan** out) {
         GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->stage), n * 4, hipDeviceMallocFinegrained));
         GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, n));
         GAB_HIP_CHECK(hipMalloc(&p->consumed, n * 4));
-        GAB_HIP_CHECK(hipMalloc(&p->counter, 256));                    // [0] workgroups finished, [32] the relayed `landed`: a line each
-        GAB_HIP_CHECK(hipMemset(p->counter, 0, 256));
+        GAB_HIP_CHECK(hipEventCreateWithFlags(&p->check_ev, hipEventDisableTiming));
+        GAB_HIP_CHECK(hipMalloc(&p->counter, 128));
+        GAB_HIP_CHECK(hipMemset(p->counter, 0, 128));
         GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->words), 64 * sizeof(unsigned), hipHostMallocDefault));
         for (int i = 0; i < 64; ++i) p->words[i] = 0;
         GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
@@ -503,10 +484,43 @@ void gab_link_plan_destroy(gab_link_plan* p) {
     delete p;
 }
 
+static int gab_link_finish_check(gab_link_plan* p, const char* who) {
+    if (!p->check_pending) return GAB_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;;) {
+        const hipError_t q = hipEventQuery(p->check_ev);
+        if (q == hipSuccess) break;
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) GAB_HIP_CHECK(q);
+        if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+            gab::set_last_error(std::string(who) + ": the check launch behind the previous round trip did not end within 4 s");
+            return GAB_ERR_RUNTIME;
+        }
+    }
+    p->check_pending = false;
+    const unsigned verdict = __atomic_load_n(&p->words[48], __ATOMIC_ACQUIRE);
+    p->words[48] = 0;
+    if (verdict & gab::kLinkErrTorn) {
+        gab::set_last_error(std::string(who) + ": a word the round trip's kernel consumed while the upload was still running is not the word the completed "
+                            "upload left in the staging buffer (an engine write that landed in pieces or out of order): the output of THAT round trip was wrong");
+        return GAB_ERR_RUNTIME;
+    }
+    return GAB_OK;
+}
+
+int gab_datatransfer_round_trip_check(gab_link_plan* p) {
+    return gab::guarded([&]() -> int {
+        if (!p) return gab::bad_arg("gab_datatransfer_round_trip_check: null plan");
+        return gab_link_finish_check(p, "gab_datatransfer_round_trip_check");
+    });
+}
+
 int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_out, int in_size, int out_size,
                                 gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_datatransfer_round_trip: null plan");
+        // the previous call's check launch: its verdict, and the sentinel it puts back, come before this call's upload
+        if (int rc0 = gab_link_finish_check(p, "gab_datatransfer_round_trip (the previous call)")) return rc0;
         if (in_size < 0 || out_size < 0) return gab::bad_arg("gab_datatransfer_round_trip: negative size");
         if (in_size > p->max_in) return gab::bad_arg("gab_datatransfer_round_trip: in_size exceeds the plan's max_in_size");
         if ((!h_in && in_size) || (!h_out && out_size)) return gab::bad_arg("gab_datatransfer_round_trip: null pointer");
@@ -570,7 +584,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         volatile unsigned* const done = p->words;
         unsigned* const landed = p->words + 16;
         volatile unsigned* const error = p->words + 32;
-        gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, p->consumed, p->counter + 32, epoch, in_size, out_size};
+        gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, p->consumed, epoch, in_size, out_size};
         // the launch carries its own stop event: what the call returns on (k_conv_accel.hip, kRtCompletion: the cheapest of
         // the stated ways to learn that a launch has ended, profiles/r05_roundtrip_completion.txt)
         hipExtLaunchKernelGGL(gab::datatransfer_round_trip_kernel, dim3(p->workgroups), dim3(gab::kBlock), 0, s, nullptr, p->done_ev, 0, rt);
@@ -581,6 +595,8 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(p->copy_stream);
             (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, (size_t)std::max(p->max_in, 4));
+            p->words[48] = 0;                              // (a check launch over words that never landed says nothing)
+            p->check_pending = false;
             (void)hipDeviceSynchronize();
             p->stale_lo = p->stale_hi = 0;
         };
@@ -590,6 +606,15 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         }
         p->epoch = epoch;
         if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
+        if (upload && dep > 0) {
+            // the check launch: behind the main launch on its stream AND behind the upload's completion event
+            if (streamed) GAB_HIP_CHECK(hipStreamWaitEvent(s, p->copy_ev, 0));
+            gab::datatransfer_round_trip_check_kernel<<<dim3(std::min(256, (dep + gab::kBlock - 1) / gab::kBlock)), dim3(gab::kBlock), 0, s>>>(
+                p->stage, p->consumed, p->words + 48, dep);
+            if (int rc2 = gab::launch_status("datatransfer_round_trip_check_kernel")) return rc2;
+            GAB_HIP_CHECK(hipEventRecord(p->check_ev, s));
+            p->check_pending = true;
+        }
         // The upload's event releases workgroups whose words really hold the sentinel (`landed`: a release store the kernel
         // acquires); the hint word says when the launch is about to end; the call returns when the launch HAS ended
         // (its stop event) and the upload is through (an input longer than the output is still landing when the last
@@ -627,12 +652,9 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             }
         }
         if (*error != 0 || *done != epoch) {
-            const bool torn = (*error & gab::kLinkErrTorn) != 0;
             *error = 0;
             repoison();
-            gab::set_last_error(torn ? "gab_datatransfer_round_trip: a word the kernel consumed while the upload was still running is not the word the completed upload "
-                                       "left in the staging buffer (an engine write that landed in pieces or out of order); the output of this call is invalid"
-                                     : "gab_datatransfer_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
+            gab::set_last_error("gab_datatransfer_round_trip: a workgroup waited about a second for its input and gave up; the output of this call is invalid");
             return GAB_ERR_RUNTIME;
         }
         return GAB_OK;

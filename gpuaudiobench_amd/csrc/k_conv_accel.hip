@@ -644,7 +644,6 @@ struct ConvRoundTrip {
     unsigned* done;                   // pinned host: the epoch, once the last share has been drained (a HINT: the call waits for the launch's end)
     const unsigned* landed;           // pinned host: the epoch, once the host has seen the upload complete
     unsigned* error;                  // pinned host: bit 0 a wait ran out, bit 1 a consumed word is not what the completed upload left (kRtErrTorn)
-    unsigned* relay;                  // device: `landed` as workgroup 0 last saw it (the other workgroups ask this word, not the host)
     unsigned epoch;
     int groups;
     unsigned bound[kRtMaxGroups + 1];   // group g = pairs [bound[g], bound[g + 1]): equal groups, the first and the last cut finer (see gab_conv_round_trip_init)
@@ -667,25 +666,34 @@ __device__ __forceinline__ unsigned rt_peek(const unsigned* p) {
 // Round 6: what a workgroup consumed EARLY is checked against what the COMPLETED upload left.  The hand-off above rests on two
 // observations — an engine packet writes a naturally aligned word whole, and a word never shows an intermediate value — and
 // a violation was silent wrong audio (profiles/r05_incident_torn_word.txt was one: found by a stress run, not by the
-// call).  The consumed words stay in the staging buffer until the host's release of `landed` (the copy's completion: its
-// writes are final and visible) has been ACQUIRED; they are then read again and compared with what was consumed, and only
-// then does the sentinel go back.  A difference sets kRtErrTorn and the call returns GAB_ERR_RUNTIME like a wait that ran out.
-// `landed` lives in pinned host memory: workgroup 0's first wave asks the host and passes the word on through `relay`
-// (device memory), everybody else asks the relay.  The last channel group's workgroups find it set when they park their
-// outputs (the copy ended ten microseconds earlier) and read their words again under the drain; earlier groups wait at
-// their end, off the launch's critical path.
+// call).  The consumed words stay in the staging buffer — the kernel no longer puts the sentinel back — and a second, small
+// launch behind it on the same stream, ordered behind the UPLOAD'S OWN COMPLETION EVENT (hipStreamWaitEvent: a completed
+// copy's writes are final and visible), reads every word again, compares it with what the kernel consumed (the plan's
+// newest history block: the consumed words, bit for bit) and only then puts the sentinel back: conv_round_trip_check_kernel.
+// Why not inside the kernel: the earliest statement "the upload is complete" that reaches a running kernel — the host's
+// release of `landed` behind hipEventQuery, or a four-byte copy queued behind the upload's last piece — arrives 14-20 us
+// after the last byte (both go through the command processor), and a launch that waits for it ends that much later:
+// 87-90 us per call against 69 (profiles/r06_roundtrip_check.txt).  The check launch costs the CALL nothing: the call
+// returns on the main launch's end as before; the check's verdict is read by the next call on the plan (which waits for it:
+// its upload must not meet the re-arming stores), by gab_conv_round_trip_check, or — gab_conv_round_trip_set_check(plan, 2) —
+// by the call itself, which then returns ~10 us later and reports a torn word AT the failing call.
 constexpr unsigned kRtErrWait = 1u, kRtErrTorn = 2u;
-// has the host announced the upload's completion?  (wave-uniform; an ACQUIRE: loads issued after a `true` see the final words)
-__device__ __forceinline__ bool rt_landed(const ConvRoundTrip& rt, bool ask_host) {
-    if (ask_host) {
-        const unsigned h = __hip_atomic_load(rt.landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (h == rt.epoch) {
-            __hip_atomic_store(rt.relay, h, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            return true;
-        }
-        return false;
-    }
-    return __hip_atomic_load(rt.relay, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == rt.epoch;
+
+// the consumed words (the newest block of the history ring, as conv_round_trip_kernel stored them) against the staging buffer
+// after the upload's completion; then the sentinel goes back for the next buffer
+__global__ __launch_bounds__(kThreads) void conv_round_trip_check_kernel(unsigned* __restrict__ stage, const float* __restrict__ hist,
+                                                                        unsigned* __restrict__ verdict, int slot) {
+    const int tid = threadIdx.x, q = blockIdx.x;
+    const cf* const hp = reinterpret_cast<const cf*>(hist) + ((size_t)q * kSlots + slot) * kB;
+    unsigned* const row = stage + (size_t)(2 * q) * kB;                              // the pair's two rows, contiguous
+    const cf c0 = hp[tid], c1 = hp[tid + kThreads];                                 // (channel a, channel b) of samples tid, tid + 256
+    const unsigned v0 = rt_peek(row + tid), v1 = rt_peek(row + tid + kThreads), v2 = rt_peek(row + kB + tid), v3 = rt_peek(row + kB + tid + kThreads);
+    const bool torn = v0 != __float_as_uint(c0.x) || v2 != __float_as_uint(c0.y) || v1 != __float_as_uint(c1.x) || v3 != __float_as_uint(c1.y);
+    if (torn) __hip_atomic_fetch_or(verdict, kRtErrTorn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(row + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(row + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(row + kB + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(row + kB + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
@@ -777,7 +785,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     }
     GAB_RT_STAMP_MAX(g, 1);
     if (gave_up) __hip_atomic_store(rt.error, kRtErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // (the words stay where they are until they have been checked against the completed upload: verify_and_rearm below)
+    // (the words stay where they are: conv_round_trip_check_kernel, behind the upload's completion, compares them with what
+    // was taken here and puts the sentinel back)
 
     // ---- near partition: [block k-1 | block k]
     cf za[4];
@@ -808,54 +817,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
         __hip_atomic_store(p0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // Is the upload known to be complete by now?  (The last groups: yes.)  Then this wave's four words are asked for again
-    // behind the barrier — behind the acquire — and travel under the drain; otherwise at the end.
-    const bool ask_host = blockIdx.x == 0 && tid < kWave;         // workgroup 0's first wave talks to the host
-    const bool landed_at_park = !gave_up && rt_landed(rt, ask_host);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its own stores
     __syncthreads();
-    bool checked_early = false;
-    unsigned v[4] = {0, 0, 0, 0};
-    if (landed_at_park) {
-        checked_early = true;
-        v[0] = rt_peek(row + tid);
-        v[1] = rt_peek(row + tid + kThreads);
-        v[2] = rt_peek(row + kB + tid);
-        v[3] = rt_peek(row + kB + tid + kThreads);
-    }
     GAB_RT_STAMP_MAX(g, 2);
-    // the consumed words against the completed upload's, then the sentinel goes back for the next buffer (before this launch ends)
-    auto verify_and_rearm = [&]() {
-        if (!gave_up) {
-            if (!checked_early) {
-                int tries = 0;
-                while (!rt_landed(rt, ask_host)) {
-                    if (++tries > kRtPollLimit) { gave_up = true; break; }
-                    if (ask_host) __builtin_amdgcn_s_sleep(30); else __builtin_amdgcn_s_sleep(10);
-                }
-                if (gave_up) {
-                    __hip_atomic_store(rt.error, kRtErrWait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else {
-                    v[0] = rt_peek(row + tid);
-                    v[1] = rt_peek(row + tid + kThreads);
-                    v[2] = rt_peek(row + kB + tid);
-                    v[3] = rt_peek(row + kB + tid + kThreads);
-                }
-            }
-            if (!gave_up && (v[0] != w[0] || v[1] != w[1] || v[2] != w[2] || v[3] != w[3]))
-                __hip_atomic_fetch_or(rt.error, kRtErrTorn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        __hip_atomic_store(const_cast<unsigned*>(row) + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(const_cast<unsigned*>(row) + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(const_cast<unsigned*>(row) + kB + tid + kThreads, kRtSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    // ---- the group's slab goes to the pinned output in whole rows of the group's width, shared out among the group's
-    // own workgroups: a slab of `members` pairs is members x 256 float4, one SHARE = 256 consecutive float4 = one per
-    // thread.  Words per group (a 128-byte line each): [0] arrivals (runs on from launch to launch), [1] shares claimed
-    // (zeroed by the last arriver before it announces), [2] the epoch once every member is parked.  A workgroup that
-    // arrives early waits for [2] — bounded, and if it gives up it simply leaves: shares are claimed, not owned, and the
-    // LAST arriver (who never waits) keeps claiming until none is left.  Nobody waits for a workgroup that has not started.
     const int first = rt.bound[g];
     const int members = (int)rt.bound[g + 1] - first;
     unsigned* const gw = rt.counters + 32 * g;
@@ -878,7 +842,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
     }
     __syncthreads();
     const int role = s_word;
-    if (role == 0) { verify_and_rearm(); return; }
+    if (role == 0) return;
     const int row_f4 = members / 2;                              // float4 per row (members is even: T % 4 == 0)
     const auto srd = __builtin_amdgcn_make_buffer_rsrc(rt.park, 0, (int)((size_t)T * kB * 4), 0x00020000);
     const int col0 = 2 * first;
@@ -912,7 +876,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_round_trip_kernel(
             GAB_RT_STAMP_MAX(64, 0);
         }
     }
-    verify_and_rearm();                                          // (behind the hint: the host goes on to wait for the launch's END, which is behind this)
 }
 
 // The launch carries n_buffers consecutive buffers (in/out are [n][T*B]); a workgroup walks them
@@ -3132,10 +3095,17 @@ struct gab_conv_plan {
     size_t carry_bytes = 0;
     bool fresh = true;        // nothing has run since the last reset
     // gab_conv_round_trip (classic cut): created at its first call
-    unsigned* rt_stage = nullptr;       // fine-grained device memory the upload lands in
+    unsigned* rt_stage = nullptr;       // fine-grained device memory the upload lands in: TWO buffers [2][T*B], taken in turn (call parity) — the
+                                        // check launch behind call k re-arms buffer k & 1 while call k + 1 is already filling the other
     float* rt_park = nullptr;           // device: outputs until their channel group is complete
     unsigned* rt_counters = nullptr;    // device: per-group arrivals, groups drained
-    unsigned* rt_words = nullptr;       // pinned host: [0] done, [16] landed, [32] error (a 64-byte line each)
+    unsigned* rt_words = nullptr;       // pinned host: [0] done, [16] landed, [32] error, [48] the check launch's verdict (a 64-byte line each)
+    hipStream_t rt_check_stream = nullptr;            // the check launches' own stream: behind the main launch and the upload by events, not in the
+                                                      // caller's stream (the next call's main launch must not stand behind a check that waits for an upload's event)
+    hipEvent_t rt_main_ev = nullptr;                  // behind the main launch, for the check launch to wait on
+    hipEvent_t rt_check_ev[2] = {nullptr, nullptr};   // behind conv_round_trip_check_kernel, per staging buffer (verdicts: rt_words[48], rt_words[56])
+    bool rt_check_pending[2] = {false, false};        // a check launch has been queued and its verdict not yet read
+    int rt_check_mode = 1;              // gab_conv_round_trip_set_check: 0 the verdict is ignored (the check launch still puts the sentinel back), 1 read at the next call, 2 read in the call
     hipStream_t rt_copy_stream = nullptr;
     hipEvent_t rt_copy_ev = nullptr;
     hipEvent_t rt_done_ev = nullptr;      // the launch's own completion (what gab_conv_round_trip returns on)
@@ -3285,6 +3255,9 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->rt_stage) (void)hipFree(p->rt_stage);
     if (p->rt_park) (void)hipFree(p->rt_park);
     if (p->rt_counters) (void)hipFree(p->rt_counters);
+    for (hipEvent_t e : p->rt_check_ev) if (e) (void)hipEventDestroy(e);
+    if (p->rt_main_ev) (void)hipEventDestroy(p->rt_main_ev);
+    if (p->rt_check_stream) (void)hipStreamDestroy(p->rt_check_stream);
     if (p->rt_words) (void)hipHostFree(p->rt_words);
     if (p->eng_in) (void)hipFree(p->eng_in);
     if (p->eng_out) (void)hipFree(p->eng_out);
@@ -3353,6 +3326,12 @@ int gab_conv_reset(gab_conv_plan* p, gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_conv_reset: null plan");
         if (p->eng_running) return gab::bad_arg("gab_conv_reset: the plan's engine is running (gab_conv_engine_stop first)");
+        for (int b = 0; b < 2; ++b)                            // (a reset starts the stream anew: the last round trips' verdicts no longer matter)
+            if (p->rt_check_pending[b]) {
+                (void)hipEventSynchronize(p->rt_check_ev[b]);
+                p->rt_check_pending[b] = false;
+                p->rt_words[48 + 8 * b] = 0;
+            }
         hipStream_t s = gab::as_stream(stream);
         {
             // launches still in flight on other streams read the rings: the memsets go behind them
@@ -3461,8 +3440,8 @@ int gab_conv_process(gab_conv_plan* p, const float* d_in, float* d_out, int mode
 // The staging buffers, counters and the upload stream of gab_conv_round_trip.
 static void gab_conv_round_trip_init(gab_conv_plan* p) {
     const size_t n = (size_t)p->tracks * p->bufsize;
-    GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->rt_stage), n * 4, hipDeviceMallocFinegrained));
-    GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, n));
+    GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->rt_stage), 2 * n * 4, hipDeviceMallocFinegrained));
+    GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, 2 * n));
     GAB_HIP_CHECK(hipMalloc(&p->rt_park, n * 4));
     int groups = 16;                                  // 64 channels = 256-byte rows at 1024 channels
     int taper = 1;                                    // the first and the last group cut into quarter, quarter, half (round 5)
@@ -3494,8 +3473,11 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     p->rt_groups = (int)fine.size();
     p->rt_bound[0] = 0;
     for (int g = 0; g < p->rt_groups; ++g) p->rt_bound[g + 1] = p->rt_bound[g] + (unsigned)fine[g];
-    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 2)));      // a 128-byte line per group, one for the shares drained, one for the relayed `landed`
-    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 2)));
+    GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 1)));      // a 128-byte line per group, one for the shares drained
+    GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 1)));
+    for (hipEvent_t& e : p->rt_check_ev) GAB_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_main_ev, hipEventDisableTiming));
+    GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_check_stream, hipStreamNonBlocking));
     GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
     for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
     GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
@@ -3503,6 +3485,51 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_done_ev, hipEventDisableTiming));
     GAB_HIP_CHECK(hipDeviceSynchronize());
     p->rt_epoch = 0;
+}
+
+// The verdict of the last check launch (conv_round_trip_check_kernel): waits for it (it runs a few microseconds behind the call
+// that queued it), GAB_OK or GAB_ERR_RUNTIME with the message.  The plan's next upload must come behind it either way: the
+// check launch is what puts the sentinel back.
+static int gab_conv_round_trip_finish_check(gab_conv_plan* p, int b, bool wait, const char* who) {
+    if (!p->rt_check_pending[b]) return GAB_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;;) {
+        const hipError_t q = hipEventQuery(p->rt_check_ev[b]);
+        if (q == hipSuccess) break;
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) GAB_HIP_CHECK(q);
+        if (!wait) return GAB_OK;                                  // (still running: its verdict is read later)
+        if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
+            gab::set_last_error(std::string(who) + ": the check launch behind an earlier round trip did not end within 4 s");
+            return GAB_ERR_RUNTIME;
+        }
+    }
+    p->rt_check_pending[b] = false;
+    const unsigned verdict = __atomic_load_n(&p->rt_words[48 + 8 * b], __ATOMIC_ACQUIRE);
+    p->rt_words[48 + 8 * b] = 0;
+    if (p->rt_check_mode != 0 && (verdict & gab::kRtErrTorn)) {
+        gab::set_last_error(std::string(who) + ": a word the round trip's kernel consumed while the upload was still running is not the word the "
+                            "completed upload left in the staging buffer (an engine write that landed in pieces or out of order): the output of THAT "
+                            "round trip was wrong and so is the plan's carried history (gab_conv_reset before the stream goes on)");
+        return GAB_ERR_RUNTIME;
+    }
+    return GAB_OK;
+}
+
+int gab_conv_round_trip_check(gab_conv_plan* p) {
+    return gab::guarded([&]() -> int {
+        if (!p) return gab::bad_arg("gab_conv_round_trip_check: null plan");
+        const int r0 = gab_conv_round_trip_finish_check(p, 0, true, "gab_conv_round_trip_check");
+        const int r1 = gab_conv_round_trip_finish_check(p, 1, true, "gab_conv_round_trip_check");
+        return r0 ? r0 : r1;
+    });
+}
+
+int gab_conv_round_trip_set_check(gab_conv_plan* p, int mode) {
+    if (!p) return gab::bad_arg("gab_conv_round_trip_set_check: null plan");
+    if (mode < 0 || mode > 2) return gab::bad_arg("gab_conv_round_trip_set_check: 0 (ignore the verdict), 1 (read it at the next call / gab_conv_round_trip_check), 2 (read it in the call)");
+    p->rt_check_mode = mode;
+    return GAB_OK;
 }
 
 int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_stream_t stream) {
@@ -3531,6 +3558,15 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             return GAB_OK;
         }
         if (!p->rt_stage) gab_conv_round_trip_init(p);
+        // The staging buffers take turns: this call fills buffer (epoch + 1) & 1, whose check launch (queued two calls ago: it
+        // puts the sentinel back) must be through — waited for; the OTHER buffer's check (the previous call's) is looked at
+        // without waiting: a paced caller finds its verdict here, a back-to-back caller one call later.
+        {
+            const int mine = (int)((p->rt_epoch + 1) & 1u);
+            const int ra = gab_conv_round_trip_finish_check(p, mine, true, "gab_conv_round_trip (an earlier call)");
+            const int rb = gab_conv_round_trip_finish_check(p, mine ^ 1, false, "gab_conv_round_trip (the previous call)");
+            if (ra || rb) return ra ? ra : rb;
+        }
         if (p->rt_checked_out != h_out) {              // the kernel writes h_out itself: it must be mapped into the device
             if (!mapped(h_out))
                 return gab::bad_arg("gab_conv_round_trip: h_out must be pinned host memory (hipHostMalloc) or device memory");
@@ -3541,6 +3577,8 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         // the device counters run on from launch to launch and are compared with epoch x members: the plan's epoch moves
         // only when a launch has really been made
         const unsigned epoch = p->rt_epoch + 1;
+        const int buf = (int)(epoch & 1u);                                           // this call's staging buffer
+        unsigned* const stage = p->rt_stage + (size_t)buf * p->tracks * p->bufsize;
         volatile unsigned* const done = p->rt_words;
         unsigned* const landed = p->rt_words + 16;
         volatile unsigned* const error = p->rt_words + 32;
@@ -3564,7 +3602,10 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         auto rearm_stage = [&]() {
             (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(p->rt_copy_stream);
-            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, (size_t)p->tracks * p->bufsize);
+            (void)hipStreamSynchronize(p->rt_check_stream);
+            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, 2 * (size_t)p->tracks * p->bufsize);
+            p->rt_words[48] = p->rt_words[56] = 0;      // (check launches over words that never landed say nothing)
+            p->rt_check_pending[0] = p->rt_check_pending[1] = false;
             (void)hipDeviceSynchronize();
         };
         // The engine copy goes out in pieces of kRtUploadPiece bytes, a multiple of four: the runtime cuts a copy into engine
@@ -3580,7 +3621,7 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
 #endif
         auto upload_range = [&](size_t lo, size_t hi) {
             for (size_t off = lo; off < hi; off += gab::kRtUploadPiece)
-                GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->rt_stage) + off, reinterpret_cast<const char*>(h_in) + off,
+                GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(stage) + off, reinterpret_cast<const char*>(h_in) + off,
                                              std::min(gab::kRtUploadPiece, hi - off), hipMemcpyHostToDevice, p->rt_copy_stream));
         };
         auto upload_pieces = [&]() {
@@ -3590,7 +3631,7 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             // upload leaves it out, and the right value goes up only when the rest is through, just before `landed` is released:
             // the consumed word differs from what the completed upload left, and the call must say so.
             unsigned wrong = reinterpret_cast<const unsigned*>(h_in)[tear] ^ 0x00010000u;
-            GAB_HIP_CHECK(hipMemcpy(p->rt_stage + tear, &wrong, 4, hipMemcpyHostToDevice));
+            GAB_HIP_CHECK(hipMemcpy(stage + tear, &wrong, 4, hipMemcpyHostToDevice));
             upload_range(0, (size_t)tear * 4);
             upload_range((size_t)tear * 4 + 4, bytes);
         };
@@ -3602,8 +3643,8 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         } else if (upload) {
             upload_pieces();
         }
-        gab::ConvRoundTrip rt{p->rt_stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
-                              p->rt_counters + 32 * (p->rt_groups + 1), epoch, p->rt_groups, {}};
+        gab::ConvRoundTrip rt{stage, p->rt_park, h_out, p->rt_counters, p->rt_words, p->rt_words + 16, p->rt_words + 32,
+                              epoch, p->rt_groups, {}};
         for (int g = 0; g <= p->rt_groups; ++g) rt.bound[g] = p->rt_bound[g];
         if (completion == 2)
             hipExtLaunchKernelGGL(gab::conv_round_trip_kernel, dim3(p->pairs), dim3(gab::kThreads), 0, s, nullptr, p->rt_done_ev, 0,
@@ -3618,6 +3659,20 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         }
         p->rt_epoch = epoch;
         if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
+        // the check launch, on a stream of its own: behind the main launch (an event recorded behind it) AND behind the upload's
+        // completion event; compares the words the main launch consumed (the history ring's newest block) with what the
+        // completed upload left, puts the sentinel back
+        const int consumed_slot = p->head;
+        GAB_HIP_CHECK(hipEventRecord(p->rt_main_ev, s));
+        auto queue_check = [&]() {
+            GAB_HIP_CHECK(hipStreamWaitEvent(p->rt_check_stream, p->rt_main_ev, 0));
+            if (upload && streamed) GAB_HIP_CHECK(hipStreamWaitEvent(p->rt_check_stream, p->rt_copy_ev, 0));
+            gab::conv_round_trip_check_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, p->rt_check_stream>>>(stage, p->hist, p->rt_words + 48 + 8 * buf, consumed_slot);
+            if (gab::launch_status("conv_round_trip_check_kernel")) throw std::runtime_error(gab::last_error());
+            GAB_HIP_CHECK(hipEventRecord(p->rt_check_ev[buf], p->rt_check_stream));
+            p->rt_check_pending[buf] = true;
+        };
+        if (upload && tear < 0) queue_check();          // (diagnostic GAB_RT_TEAR: behind the late word, below)
         p->head = (p->head + 1) & (gab::kSlots - 1);
         p->fresh = false;
         // After a wait that ran out, words may land behind the sentinel the kernel put back and the kernel has taken
@@ -3643,8 +3698,10 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         while (!told || *done != epoch) {
             if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) {
                 if (tear >= 0) {                            // (diagnostic builds) the word's right value, late
-                    GAB_HIP_CHECK(hipMemcpyAsync(p->rt_stage + tear, reinterpret_cast<const unsigned*>(h_in) + tear, 4, hipMemcpyHostToDevice, p->rt_copy_stream));
+                    GAB_HIP_CHECK(hipMemcpyAsync(stage + tear, reinterpret_cast<const unsigned*>(h_in) + tear, 4, hipMemcpyHostToDevice, p->rt_copy_stream));
+                    GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));   // (recorded again: behind the late word)
                     GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
+                    queue_check();
                 }
                 __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);
                 told = true;
@@ -3668,11 +3725,10 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
                     return after_a_failed_wait("the launch did not end within 4 s");
             }
         }
-        if (*error & gab::kRtErrTorn)
-            return after_a_failed_wait("a word the kernel consumed while the upload was still running is not the word the completed upload left in "
-                                       "the staging buffer (an engine write that landed in pieces or out of order)");
         if (*error != 0) return after_a_failed_wait("a workgroup waited about a second for its input and gave up");
         if (*done != epoch) return after_a_failed_wait("the launch ended without draining every channel group");
+        if (p->rt_check_mode == 2)                               // the check's verdict AT this call (it ends when the upload's event has gone through the command processor)
+            if (int rc2 = gab_conv_round_trip_finish_check(p, buf, true, "gab_conv_round_trip")) return rc2;
         if (p->warm_on) (void)gab_keep_warm_kick(p->warm);       // the result is out: keep the device from going idle until the next slot
         return GAB_OK;
     });
@@ -4086,7 +4142,7 @@ int gab_conv_state_bytes(const gab_conv_plan* p, size_t* spectra, size_t* histor
 int gab_debug_rt_stage_dirty(gab_conv_plan* p, long long* first_index) {
     if (!p || !p->rt_stage) return -1;
     (void)hipDeviceSynchronize();
-    const size_t n = (size_t)p->tracks * p->bufsize;
+    const size_t n = 2 * (size_t)p->tracks * p->bufsize;          // both staging buffers
     std::vector<unsigned> h(n);
     if (hipMemcpy(h.data(), p->rt_stage, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     int dirty = 0;

@@ -154,6 +154,10 @@ class LinkPlan:
                                               h_in.numel(), h_out.numel(), st))
         return h_out
 
+    def check(self):
+        """The verdict of the check launch behind the last round trip (gab_datatransfer_round_trip_check)."""
+        check(lib.gab_datatransfer_round_trip_check(self._h))
+
     def close(self):
         if self._h:
             lib.gab_link_plan_destroy(self._h)
@@ -279,6 +283,15 @@ class ConvPlan:
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         check(lib.gab_conv_round_trip(self._h, C.c_void_p(h_in.data_ptr()), C.c_void_p(h_out.data_ptr()), st))
         return h_out
+
+    def round_trip_check(self):
+        """The verdict of the check launch behind the last round trip (gab_conv_round_trip_check): raises if a word the
+        kernel consumed early is not what the completed upload left."""
+        check(lib.gab_conv_round_trip_check(self._h))
+
+    def round_trip_set_check(self, mode):
+        """0 ignore the verdict, 1 (default) read it at the next call / round_trip_check(), 2 read it in the call."""
+        check(lib.gab_conv_round_trip_set_check(self._h, int(mode)))
 
     def round_trip_keep_warm(self, on=True):
         """Every later round trip of this plan ends with a keep-warm kick (gab_conv_round_trip_keep_warm)."""

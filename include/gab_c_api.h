@@ -79,6 +79,12 @@ int gab_link_plan_create(int max_in_size, gab_link_plan** out);
 void gab_link_plan_destroy(gab_link_plan* plan);
 int gab_datatransfer_round_trip(gab_link_plan* plan, const float* h_in, float* h_out, int in_size, int out_size,
                                 gab_stream_t stream);
+/* The kernel takes input words while the upload is still running: that rests on engine writes landing whole and once (an
+ * observation).  Since round 6 a second, small launch behind every call — ordered behind the upload's completion event —
+ * compares what the kernel took with what the COMPLETED upload left and puts the staging buffer back; it costs the call
+ * nothing (the call returns on the main launch's end).  Its verdict is read by the plan's NEXT call (which returns
+ * GAB_ERR_RUNTIME: the PREVIOUS call's output was wrong) or by this function (waits a few microseconds for the check).   */
+int gab_datatransfer_round_trip_check(gab_link_plan* plan);
 
 /* ---- keep-warm (additive; no counterpart in the reference, whose iterations run back to back) ---------------------
  * A device left idle for a DAW slot (512 / 48000 s = 10.667 ms) answers the next call later than one that has just been
@@ -273,6 +279,23 @@ int gab_conv_process_batch(gab_conv_plan* plan, const float* d_in, float* d_out,
  * the staging buffer has been re-armed, the next call works.  A launch that could not be made leaves the plan as it
  * was (history, epoch, staging buffer).                                                                      */
 int gab_conv_round_trip(gab_conv_plan* plan, const float* h_in, float* h_out, gab_stream_t stream);
+/* The overlapped round trip's kernel takes input words while the upload is still running: that rests on engine writes landing
+ * whole and once (an observation; a violation was silent wrong audio once: profiles/r05_incident_torn_word.txt).  Since round 6
+ * a second, small launch behind every call — on the same stream, ordered behind the UPLOAD'S COMPLETION EVENT — compares the
+ * words the kernel consumed (the plan's newest history block) with what the completed upload left in the staging buffer and
+ * only then re-arms the buffer.  It costs the call nothing: the call returns on the main launch's end, as before.
+ *   set_check(plan, 1)  (default) the verdict is read by a FOLLOWING gab_conv_round_trip on the plan — the next one when the
+ *                       check launch is through by then (one call per audio slot), the one after it for back-to-back calls
+ *                       (the plan has two staging buffers, taken in turn, so that no call waits for the previous call's check) —
+ *                       which then returns GAB_ERR_RUNTIME: an EARLIER buffer's output was wrong, gab_conv_reset before the
+ *                       stream goes on; or by gab_conv_round_trip_check (after the last buffer of a stream);
+ *   set_check(plan, 2)  the call itself waits for the verdict (15-20 us more per call: the upload's completion event goes
+ *                       through the command processor) and fails AT the call;
+ *   set_check(plan, 0)  the verdict is ignored (the check launch still re-arms the buffer).
+ * (The check cannot run INSIDE the kernel for free: the earliest "the upload is complete" that reaches a running kernel
+ * arrives 14-20 us after the last byte — measured both ways, profiles/r06_roundtrip_check.txt.)                              */
+int gab_conv_round_trip_check(gab_conv_plan* plan);
+int gab_conv_round_trip_set_check(gab_conv_plan* plan, int mode);
 /* Every later gab_conv_round_trip of this plan ends with a gab_keep_warm_kick (see keep-warm above); on = 0 stops kicking. */
 int gab_conv_round_trip_keep_warm(gab_conv_plan* plan, int on);
 /* gab_keep_warm_placement of the plan's own keep-warm launch (started = 0 if the plan has none). */

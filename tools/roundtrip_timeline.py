@@ -28,13 +28,16 @@ for _ in range(101):
     t00 = a[:G, 0].min()
     rel = (a[:G].astype(np.int64) - np.int64(t00)) / 100.0          # us
     done = (np.int64(a[64, 0]) - np.int64(t00)) / 100.0
-    rows.append(np.concatenate([rel.ravel(), [done]]))
-rows = np.median(np.array(rows), axis=0)
-G = (len(rows) - 1) // 4
+    extra = [(np.int64(a[64, k]) - np.int64(t00)) / 100.0 if a[64, k] not in (np.uint64(0), np.uint64(0xffffffffffffffff)) else np.nan for k in (1, 2, 3)]
+    rows.append(np.concatenate([rel.ravel(), [done], extra]))
+rows = np.nanmedian(np.array(rows), axis=0)
+G = (len(rows) - 4) // 4
 print("gab_conv_round_trip, %d channels, %d groups of %d channels: host clock p50 %.1f us (p95 %.1f) per call" % (
     T, G, T // G, np.percentile(walls, 50), np.percentile(walls, 95)))
 print("device marks, us after the launch's first workgroup entered (median of %d calls):" % len(walls))
 print("group  entered  rows landed  drain starts  drain done")
 for g in range(G):
     print("%5d  %7.1f  %11.1f  %12.1f  %10.1f" % (g, *rows[4 * g:4 * g + 4]))
-print("completion word written at %.1f us" % rows[-1])
+print("completion word written at %.1f us" % rows[-4])
+print("the consumed words' check against the completed upload (round 6): the first waiting workgroup saw `landed` at %.1f us, the last "
+      "check at park time started at %.1f us, the last workgroup had checked and re-armed its rows at %.1f us" % (rows[-2], rows[-1], rows[-3]))
