@@ -434,13 +434,15 @@ struct gab_link_plan {
     const void* checked_out = nullptr;
     // input words an earlier call uploaded but did not consume (its input was longer than its output): they hold
     // data, not the sentinel, and a later call that reads them must find the sentinel first
-    int stale_lo = 0, stale_hi = 0;
+    int stale_lo[2] = {0, 0}, stale_hi[2] = {0, 0};     // (per staging buffer)
+    size_t side_words = 0;              // words per staging buffer: the plan holds TWO (stage, consumed), taken in turn by call parity, so that
+                                        // no call waits for the check launch of the call before it
     unsigned* consumed = nullptr;       // device: the words as the kernel took them (checked against the completed upload)
-    hipEvent_t check_ev = nullptr;      // behind datatransfer_round_trip_check_kernel (words[48]: its verdict)
-    bool check_pending = false;
+    hipEvent_t check_ev[2] = {nullptr, nullptr};      // behind datatransfer_round_trip_check_kernel, per staging buffer (verdicts: words[48], words[56])
+    bool check_pending[2] = {false, false};
     ~gab_link_plan() {
         if (consumed) (void)hipFree(consumed);
-        if (check_ev) (void)hipEventDestroy(check_ev);
+        for (hipEvent_t e : check_ev) if (e) (void)hipEventDestroy(e);
         if (stage) (void)hipFree(stage);
         if (counter) (void)hipFree(counter);
         if (words) (void)hipHostFree(words);
@@ -458,10 +460,11 @@ int gab_link_plan_create(int max_in_size, gab_link_plan** out) {
         std::unique_ptr<gab_link_plan> p(new gab_link_plan);
         p->max_in = max_in_size;
         const size_t n = (size_t)std::max(max_in_size, 4);
-        GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->stage), n * 4, hipDeviceMallocFinegrained));
-        GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, n));
-        GAB_HIP_CHECK(hipMalloc(&p->consumed, n * 4));
-        GAB_HIP_CHECK(hipEventCreateWithFlags(&p->check_ev, hipEventDisableTiming));
+        p->side_words = (n + 63) & ~(size_t)63;
+        GAB_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p->stage), 2 * p->side_words * 4, hipDeviceMallocFinegrained));
+        GAB_HIP_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, 2 * p->side_words));
+        GAB_HIP_CHECK(hipMalloc(&p->consumed, 2 * p->side_words * 4));
+        for (hipEvent_t& e : p->check_ev) GAB_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         GAB_HIP_CHECK(hipMalloc(&p->counter, 128));
         GAB_HIP_CHECK(hipMemset(p->counter, 0, 128));
         GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->words), 64 * sizeof(unsigned), hipHostMallocDefault));
@@ -484,22 +487,23 @@ void gab_link_plan_destroy(gab_link_plan* p) {
     delete p;
 }
 
-static int gab_link_finish_check(gab_link_plan* p, const char* who) {
-    if (!p->check_pending) return GAB_OK;
+static int gab_link_finish_check(gab_link_plan* p, int b, bool wait, const char* who) {
+    if (!p->check_pending[b]) return GAB_OK;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;;) {
-        const hipError_t q = hipEventQuery(p->check_ev);
+        const hipError_t q = hipEventQuery(p->check_ev[b]);
         if (q == hipSuccess) break;
         (void)hipGetLastError();
         if (q != hipErrorNotReady) GAB_HIP_CHECK(q);
+        if (!wait) return GAB_OK;                                  // (still running: its verdict is read later)
         if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {
-            gab::set_last_error(std::string(who) + ": the check launch behind the previous round trip did not end within 4 s");
+            gab::set_last_error(std::string(who) + ": the check launch behind an earlier round trip did not end within 4 s");
             return GAB_ERR_RUNTIME;
         }
     }
-    p->check_pending = false;
-    const unsigned verdict = __atomic_load_n(&p->words[48], __ATOMIC_ACQUIRE);
-    p->words[48] = 0;
+    p->check_pending[b] = false;
+    const unsigned verdict = __atomic_load_n(&p->words[48 + 8 * b], __ATOMIC_ACQUIRE);
+    p->words[48 + 8 * b] = 0;
     if (verdict & gab::kLinkErrTorn) {
         gab::set_last_error(std::string(who) + ": a word the round trip's kernel consumed while the upload was still running is not the word the completed "
                             "upload left in the staging buffer (an engine write that landed in pieces or out of order): the output of THAT round trip was wrong");
@@ -511,7 +515,9 @@ static int gab_link_finish_check(gab_link_plan* p, const char* who) {
 int gab_datatransfer_round_trip_check(gab_link_plan* p) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_datatransfer_round_trip_check: null plan");
-        return gab_link_finish_check(p, "gab_datatransfer_round_trip_check");
+        const int r0 = gab_link_finish_check(p, 0, true, "gab_datatransfer_round_trip_check");
+        const int r1 = gab_link_finish_check(p, 1, true, "gab_datatransfer_round_trip_check");
+        return r0 ? r0 : r1;
     });
 }
 
@@ -519,8 +525,18 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
                                 gab_stream_t stream) {
     return gab::guarded([&]() -> int {
         if (!p) return gab::bad_arg("gab_datatransfer_round_trip: null plan");
-        // the previous call's check launch: its verdict, and the sentinel it puts back, come before this call's upload
-        if (int rc0 = gab_link_finish_check(p, "gab_datatransfer_round_trip (the previous call)")) return rc0;
+        // The staging buffers take turns (k_conv_accel.hip, gab_conv_round_trip): this call's buffer must have been re-armed by
+        // the check launch queued two calls ago — waited for; the previous call's check is looked at without waiting.
+        const int buf = (int)((p->epoch + 1) & 1u);
+        {
+            const int ra = gab_link_finish_check(p, buf, true, "gab_datatransfer_round_trip (an earlier call)");
+            const int rb = gab_link_finish_check(p, buf ^ 1, false, "gab_datatransfer_round_trip (the previous call)");
+            if (ra || rb) return ra ? ra : rb;
+        }
+        unsigned* const stage = p->stage + (size_t)buf * p->side_words;
+        unsigned* const consumed = p->consumed + (size_t)buf * p->side_words;
+        int& stale_lo = p->stale_lo[buf];
+        int& stale_hi = p->stale_hi[buf];
         if (in_size < 0 || out_size < 0) return gab::bad_arg("gab_datatransfer_round_trip: negative size");
         if (in_size > p->max_in) return gab::bad_arg("gab_datatransfer_round_trip: in_size exceeds the plan's max_in_size");
         if ((!h_in && in_size) || (!h_out && out_size)) return gab::bad_arg("gab_datatransfer_round_trip: null pointer");
@@ -534,14 +550,14 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             p->checked_out = h_out;
         }
         const int dep = std::min(in_size, out_size);
-        if (p->stale_hi > p->stale_lo && dep > p->stale_lo) {
+        if (stale_hi > stale_lo && dep > stale_lo) {
             // this call reads words an earlier one left unconsumed: the sentinel goes back, ahead of the upload on its
             // stream, and the kernel's stream waits for it (steady repeats of one shape never come here)
-            GAB_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->stage + p->stale_lo), (int)gab::kLinkSentinel,
-                                            (size_t)(p->stale_hi - p->stale_lo), p->copy_stream));
+            GAB_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(stage + stale_lo), (int)gab::kLinkSentinel,
+                                            (size_t)(stale_hi - stale_lo), p->copy_stream));
             GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
             GAB_HIP_CHECK(hipStreamWaitEvent(s, p->copy_ev, 0));
-            p->stale_lo = p->stale_hi = 0;
+            stale_lo = stale_hi = 0;
         }
         bool upload = in_size > 0;
 #ifdef GAB_ABLATE
@@ -565,7 +581,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
                 const size_t watched = sizeof(float) * (size_t)dep;     // the kernel only looks at the first `dep` words: what lies beyond goes up in one copy
                 for (size_t off = 0; off < bytes;) {
                     const size_t n = off >= watched ? bytes - off : std::min(piece, bytes - off);
-                    GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(p->stage) + off, reinterpret_cast<const char*>(h_in) + off, n,
+                    GAB_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(stage) + off, reinterpret_cast<const char*>(h_in) + off, n,
                                                  hipMemcpyHostToDevice, p->copy_stream));
                     off += n;
                 }
@@ -573,8 +589,8 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
             if (!streamed) GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
         }
         if (in_size > out_size) {
-            p->stale_lo = p->stale_hi > p->stale_lo ? std::min(p->stale_lo, out_size) : out_size;
-            p->stale_hi = std::max(p->stale_hi, in_size);
+            stale_lo = stale_hi > stale_lo ? std::min(stale_lo, out_size) : out_size;
+            stale_hi = std::max(stale_hi, in_size);
         }
         if (out_size == 0) {                            // nothing comes back: the call is the upload
             GAB_HIP_CHECK(hipStreamSynchronize(p->copy_stream));
@@ -584,7 +600,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         volatile unsigned* const done = p->words;
         unsigned* const landed = p->words + 16;
         volatile unsigned* const error = p->words + 32;
-        gab::LinkRoundTrip rt{p->stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, p->consumed, epoch, in_size, out_size};
+        gab::LinkRoundTrip rt{stage, h_out, p->counter, p->words, p->words + 16, p->words + 32, consumed, epoch, in_size, out_size};
         // the launch carries its own stop event: what the call returns on (k_conv_accel.hip, kRtCompletion: the cheapest of
         // the stated ways to learn that a launch has ended, profiles/r05_roundtrip_completion.txt)
         hipExtLaunchKernelGGL(gab::datatransfer_round_trip_kernel, dim3(p->workgroups), dim3(gab::kBlock), 0, s, nullptr, p->done_ev, 0, rt);
@@ -594,11 +610,11 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         auto repoison = [&]() {
             (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(p->copy_stream);
-            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, (size_t)std::max(p->max_in, 4));
-            p->words[48] = 0;                              // (a check launch over words that never landed says nothing)
-            p->check_pending = false;
+            (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->stage), (int)gab::kLinkSentinel, 2 * p->side_words);
+            p->words[48] = p->words[56] = 0;               // (check launches over words that never landed say nothing)
+            p->check_pending[0] = p->check_pending[1] = false;
             (void)hipDeviceSynchronize();
-            p->stale_lo = p->stale_hi = 0;
+            p->stale_lo[0] = p->stale_hi[0] = p->stale_lo[1] = p->stale_hi[1] = 0;
         };
         if (rc) {
             if (upload) repoison();
@@ -606,15 +622,17 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         }
         p->epoch = epoch;
         if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->copy_ev, p->copy_stream));
-        if (upload && dep > 0) {
-            // the check launch: behind the main launch on its stream AND behind the upload's completion event
-            if (streamed) GAB_HIP_CHECK(hipStreamWaitEvent(s, p->copy_ev, 0));
+        // The check launch: queued behind the main launch on its stream by the HOST, once the host has seen the upload's completion
+        // event (k_conv_accel.hip, gab_conv_round_trip: no wait for that event is ever put into a stream)
+        auto queue_check = [&]() {
+            if (!(upload && dep > 0)) return;
             gab::datatransfer_round_trip_check_kernel<<<dim3(std::min(256, (dep + gab::kBlock - 1) / gab::kBlock)), dim3(gab::kBlock), 0, s>>>(
-                p->stage, p->consumed, p->words + 48, dep);
-            if (int rc2 = gab::launch_status("datatransfer_round_trip_check_kernel")) return rc2;
-            GAB_HIP_CHECK(hipEventRecord(p->check_ev, s));
-            p->check_pending = true;
-        }
+                stage, consumed, p->words + 48 + 8 * buf, dep);
+            if (gab::launch_status("datatransfer_round_trip_check_kernel")) throw std::runtime_error(gab::last_error());
+            GAB_HIP_CHECK(hipEventRecord(p->check_ev[buf], s));
+            p->check_pending[buf] = true;
+        };
+        if (upload && !streamed) queue_check();            // (an upload that was complete before the launch)
         // The upload's event releases workgroups whose words really hold the sentinel (`landed`: a release store the kernel
         // acquires); the hint word says when the launch is about to end; the call returns when the launch HAS ended
         // (its stop event) and the upload is through (an input longer than the output is still landing when the last
@@ -625,7 +643,7 @@ int gab_datatransfer_round_trip(gab_link_plan* p, const float* h_in, float* h_ou
         unsigned spins = 0;
         bool ended = false;
         while (*done != epoch || !told) {
-            if (!told && hipEventQuery(p->copy_ev) == hipSuccess) { __atomic_store_n(landed, epoch, __ATOMIC_RELEASE); told = true; }
+            if (!told && hipEventQuery(p->copy_ev) == hipSuccess) { __atomic_store_n(landed, epoch, __ATOMIC_RELEASE); told = true; queue_check(); }
             if ((++spins & 1023u) == 0) {
                 if (told && hipStreamQuery(s) == hipSuccess) { ended = true; break; }
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) {

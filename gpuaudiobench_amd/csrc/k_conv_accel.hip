@@ -3100,9 +3100,6 @@ struct gab_conv_plan {
     float* rt_park = nullptr;           // device: outputs until their channel group is complete
     unsigned* rt_counters = nullptr;    // device: per-group arrivals, groups drained
     unsigned* rt_words = nullptr;       // pinned host: [0] done, [16] landed, [32] error, [48] the check launch's verdict (a 64-byte line each)
-    hipStream_t rt_check_stream = nullptr;            // the check launches' own stream: behind the main launch and the upload by events, not in the
-                                                      // caller's stream (the next call's main launch must not stand behind a check that waits for an upload's event)
-    hipEvent_t rt_main_ev = nullptr;                  // behind the main launch, for the check launch to wait on
     hipEvent_t rt_check_ev[2] = {nullptr, nullptr};   // behind conv_round_trip_check_kernel, per staging buffer (verdicts: rt_words[48], rt_words[56])
     bool rt_check_pending[2] = {false, false};        // a check launch has been queued and its verdict not yet read
     int rt_check_mode = 1;              // gab_conv_round_trip_set_check: 0 the verdict is ignored (the check launch still puts the sentinel back), 1 read at the next call, 2 read in the call
@@ -3256,8 +3253,6 @@ int gab_conv_destroy(gab_conv_plan* p) {
     if (p->rt_park) (void)hipFree(p->rt_park);
     if (p->rt_counters) (void)hipFree(p->rt_counters);
     for (hipEvent_t e : p->rt_check_ev) if (e) (void)hipEventDestroy(e);
-    if (p->rt_main_ev) (void)hipEventDestroy(p->rt_main_ev);
-    if (p->rt_check_stream) (void)hipStreamDestroy(p->rt_check_stream);
     if (p->rt_words) (void)hipHostFree(p->rt_words);
     if (p->eng_in) (void)hipFree(p->eng_in);
     if (p->eng_out) (void)hipFree(p->eng_out);
@@ -3476,8 +3471,6 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     GAB_HIP_CHECK(hipMalloc(&p->rt_counters, sizeof(unsigned) * 32 * (p->rt_groups + 1)));      // a 128-byte line per group, one for the shares drained
     GAB_HIP_CHECK(hipMemset(p->rt_counters, 0, sizeof(unsigned) * 32 * (p->rt_groups + 1)));
     for (hipEvent_t& e : p->rt_check_ev) GAB_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_main_ev, hipEventDisableTiming));
-    GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_check_stream, hipStreamNonBlocking));
     GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
     for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
     GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
@@ -3602,7 +3595,6 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         auto rearm_stage = [&]() {
             (void)hipStreamSynchronize(s);
             (void)hipStreamSynchronize(p->rt_copy_stream);
-            (void)hipStreamSynchronize(p->rt_check_stream);
             (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p->rt_stage), (int)gab::kRtSentinel, 2 * (size_t)p->tracks * p->bufsize);
             p->rt_words[48] = p->rt_words[56] = 0;      // (check launches over words that never landed say nothing)
             p->rt_check_pending[0] = p->rt_check_pending[1] = false;
@@ -3659,20 +3651,20 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
         }
         p->rt_epoch = epoch;
         if (upload && streamed) GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));
-        // the check launch, on a stream of its own: behind the main launch (an event recorded behind it) AND behind the upload's
-        // completion event; compares the words the main launch consumed (the history ring's newest block) with what the
-        // completed upload left, puts the sentinel back
+        // The check launch: queued on the caller's stream (behind the main launch) by the HOST, once the host has seen the upload's
+        // completion event — no wait for that event is ever put into a stream: the runtime maps streams onto a few hardware
+        // queues, and a barrier that waits 15-20 us for the event holds up whatever shares its queue (measured: the next call's
+        // main launch, 98 against 71 us per call in a process with many streams: profiles/r06_roundtrip_check.txt).  It compares
+        // the words the main launch consumed (the history ring's newest block) with what the completed upload left and puts
+        // the sentinel back.
         const int consumed_slot = p->head;
-        GAB_HIP_CHECK(hipEventRecord(p->rt_main_ev, s));
         auto queue_check = [&]() {
-            GAB_HIP_CHECK(hipStreamWaitEvent(p->rt_check_stream, p->rt_main_ev, 0));
-            if (upload && streamed) GAB_HIP_CHECK(hipStreamWaitEvent(p->rt_check_stream, p->rt_copy_ev, 0));
-            gab::conv_round_trip_check_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, p->rt_check_stream>>>(stage, p->hist, p->rt_words + 48 + 8 * buf, consumed_slot);
+            gab::conv_round_trip_check_kernel<<<dim3(p->pairs), dim3(gab::kThreads), 0, s>>>(stage, p->hist, p->rt_words + 48 + 8 * buf, consumed_slot);
             if (gab::launch_status("conv_round_trip_check_kernel")) throw std::runtime_error(gab::last_error());
-            GAB_HIP_CHECK(hipEventRecord(p->rt_check_ev[buf], p->rt_check_stream));
+            GAB_HIP_CHECK(hipEventRecord(p->rt_check_ev[buf], s));
             p->rt_check_pending[buf] = true;
         };
-        if (upload && tear < 0) queue_check();          // (diagnostic GAB_RT_TEAR: behind the late word, below)
+        if (upload && !streamed) queue_check();         // (an upload that was complete before the launch)
         p->head = (p->head + 1) & (gab::kSlots - 1);
         p->fresh = false;
         // After a wait that ran out, words may land behind the sentinel the kernel put back and the kernel has taken
@@ -3699,12 +3691,11 @@ int gab_conv_round_trip(gab_conv_plan* p, const float* h_in, float* h_out, gab_s
             if (!told && hipEventQuery(p->rt_copy_ev) == hipSuccess) {
                 if (tear >= 0) {                            // (diagnostic builds) the word's right value, late
                     GAB_HIP_CHECK(hipMemcpyAsync(stage + tear, reinterpret_cast<const unsigned*>(h_in) + tear, 4, hipMemcpyHostToDevice, p->rt_copy_stream));
-                    GAB_HIP_CHECK(hipEventRecord(p->rt_copy_ev, p->rt_copy_stream));   // (recorded again: behind the late word)
                     GAB_HIP_CHECK(hipStreamSynchronize(p->rt_copy_stream));
-                    queue_check();
                 }
                 __atomic_store_n(landed, epoch, __ATOMIC_RELEASE);
                 told = true;
+                queue_check();                              // the upload is complete and the host knows it: the check goes behind the main launch
             }
             if ((++spins & 1023u) == 0) {
                 if (told && hipStreamQuery(s) == hipSuccess) { ended = true; break; }      // over without the hint: a wait ran out
