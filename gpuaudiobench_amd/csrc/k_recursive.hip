@@ -1069,8 +1069,9 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                 static std::mutex slots_mu;
                 static unsigned next_slot = 0;
                 // 0: round 5's (8 lines per workgroup, staged input)   1, 2: no staging, 8 / 16 lines (r06: no faster — it was
-                // never the staging)   3, 4: the lean kernel, 8 / 16 lines (delay lines of 4 GiB and more per array: form 0)
-                int form = 3;
+                // never the staging)   3, 4, 5: the lean kernel, 8 / 16 / 4 lines per workgroup: 15.5 / 19.6 / 14.0 us against
+                // 19.6 (profiles/r06_dwg.md); delay lines of 4 GiB and more per array: form 0
+                int form = 5;
 #ifdef GAB_ABLATE
                 if (getenv("GAB_DWG_FORM")) form = atoi(getenv("GAB_DWG_FORM"));     // diagnostic builds: A/B on one box
 #endif
@@ -1090,10 +1091,12 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
 #define GAB_DWG_LEAN(UV) gab::dwg_cells_lean_kernel<UV><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, n_waveguides, n_mix, \
                                                                       bufsize, max_len, slot, (unsigned)line_bytes)
                 if (form == 5) GAB_DWG_LEAN(4);
+#ifdef GAB_ABLATE                                                // diagnostic builds: the forms that were measured and not kept
                 else if (form == 4) GAB_DWG_LEAN(16);
                 else if (form == 3) GAB_DWG_LEAN(U);
                 else if (form == 2) GAB_DWG_APPEND(16, false);
                 else if (form == 1) GAB_DWG_APPEND(U, false);
+#endif
                 else GAB_DWG_APPEND(U, true);
 #undef GAB_DWG_LEAN
 #undef GAB_DWG_APPEND
