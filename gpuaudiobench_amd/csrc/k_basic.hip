@@ -469,7 +469,11 @@ int gab_link_plan_create(int max_in_size, gab_link_plan** out) {
         GAB_HIP_CHECK(hipMemset(p->counter, 0, 128));
         GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->words), 64 * sizeof(unsigned), hipHostMallocDefault));
         for (int i = 0; i < 64; ++i) p->words[i] = 0;
-        GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        {   // (the upload's stream at the highest priority: never on a hardware queue with the caller's — k_conv_accel.hip, gab_conv_round_trip_init)
+            int lo = 0, hi = 0;
+            GAB_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            GAB_HIP_CHECK(hipStreamCreateWithPriority(&p->copy_stream, hipStreamNonBlocking, hi));
+        }
         GAB_HIP_CHECK(hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming));
         GAB_HIP_CHECK(hipEventCreateWithFlags(&p->done_ev, hipEventDisableTiming));
 #ifdef GAB_ABLATE

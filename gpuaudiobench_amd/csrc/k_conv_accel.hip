@@ -3473,7 +3473,15 @@ static void gab_conv_round_trip_init(gab_conv_plan* p) {
     for (hipEvent_t& e : p->rt_check_ev) GAB_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     GAB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p->rt_words), 64 * sizeof(unsigned), hipHostMallocDefault));
     for (int i = 0; i < 64; ++i) p->rt_words[i] = 0;
-    GAB_HIP_CHECK(hipStreamCreateWithFlags(&p->rt_copy_stream, hipStreamNonBlocking));
+    {
+        // The upload's stream at the HIGHEST priority: the runtime maps streams onto a few hardware queues per priority, and where
+        // the upload's stream shares a queue with the caller's, the main launch stands behind the copy's completion packet — the
+        // call then takes upload + kernel, 123-143 us instead of 70 (measured after an engine's streams had come and gone in the
+        // process: profiles/r06_roundtrip_check.txt).  Streams of the default priority never share a queue with it.
+        int lo = 0, hi = 0;
+        GAB_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        GAB_HIP_CHECK(hipStreamCreateWithPriority(&p->rt_copy_stream, hipStreamNonBlocking, hi));
+    }
     GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_copy_ev, hipEventDisableTiming));
     GAB_HIP_CHECK(hipEventCreateWithFlags(&p->rt_done_ev, hipEventDisableTiming));
     GAB_HIP_CHECK(hipDeviceSynchronize());

@@ -27,3 +27,17 @@ e.engine_start(8, stream=side); e.engine_stop(); e.close()
 plan = gab.ConvPlan(T, B, L, scheme="classic"); plan.set_ir(ir)
 print("after an engine has run on a side stream, default stream, set_check(1): %s" % p50(plan, None), flush=True)
 plan.close()
+# the same scenario, rule by rule, and with streams alone (the runtime maps streams onto a few hardware queues)
+for mode in (1, 0, 2, 1):
+    plan = gab.ConvPlan(T, B, L, scheme="classic"); plan.set_ir(ir); plan.round_trip_set_check(mode)
+    print("after the engine, default stream, set_check(%d): %s" % (mode, p50(plan, None)), flush=True)
+    print("after the engine, own stream,     set_check(%d): %s" % (mode, p50(plan, own)), flush=True)
+    plan.close()
+extra = [torch.cuda.Stream() for _ in range(6)]
+for st in extra:
+    with torch.cuda.stream(st):
+        torch.zeros(16, device="cuda")
+torch.cuda.synchronize()
+plan = gab.ConvPlan(T, B, L, scheme="classic"); plan.set_ir(ir)
+print("six more streams in the process, default stream, set_check(1): %s" % p50(plan, None), flush=True)
+plan.close()
