@@ -267,7 +267,7 @@ inline IirScanConsts make_scan_consts(const BiquadCoeffs& c, int M) {
 // group of 32 taps ahead in a hand-fixed order (tap_group_*); the tiles at the
 // very start of the stream — where the golden SKIPS the taps that reach before
 // sample 0 — need no select with finite taps (see the kernel).
-// Measured (tools/stamp_conv1d.py): 29 -> 11.6 clocks per tap at 1024 taps
+// Measured (profiles/r04_conv1d_stamps.txt): 29 -> 11.6 clocks per tap at 1024 taps
 // (one wave per SIMD: 2.3 instructions per tap at ~4.6 clocks each), 30 -> 17
 // at C2 (two per SIMD, LDS-bound).
 // ---------------------------------------------------------------------------
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void dwg_cells_kernel(const WG* __restrict__ w
 // and at 8 192 lines there are 16 384 of them (19.7 us for 67 MB).  Here a thread owns cell j of U consecutive lines: the
 // input is staged once per U lines, and the 2 U cell loads of a thread are all requested before the first is used.
 // Same operations per cell, same order: bit-identical.  Round 4, measured at 8 192 lines: 19.7 us (one line per workgroup,
-// three run-time modulos per cell) -> 16.9 us; the counters of that launch (tools/pmc_case.sh dwg_accel_8192): 32.7 MB
+// three run-time modulos per cell) -> 16.9 us; the counters of that launch (profiles/r04_dwg_accel_8192_pmc_means.txt): 32.7 MB
 // read + 30.3 MB written, the waves alive ~12 us of the launch's 17 = 5 TB/s while they run, VALU busy 14 % — the delay
 // lines' 2 KB pieces at DRAM rate plus a launch's ramp.  Four cells per thread as 16-byte pieces (a quarter of the
 // memory instructions): 17.7 us, not kept.
