@@ -2332,7 +2332,7 @@ constexpr int kB6Lds = 3 * kWaveImg + kLdsHalf + 2 * kBinsA * 2 + kB12Tw1Cf;    
 // One pair's six waves (forward, inverse, four far).  `tid` = the thread's index among the pair's 384, `q` = the pair, `sync` = the
 // barrier the six waves meet at (the workgroup's hardware barrier where the workgroup IS the pair; a counter in LDS where two
 // pairs share a workgroup), `wave_id` = the wave's index in the workgroup (for the diagnostic stamps only).
-template <class Sync>
+template <bool LEAN_TW, class Sync>
 __device__ __forceinline__ void conv_split_pair_resident(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0, int n_buffers,
@@ -2370,8 +2370,21 @@ __device__ __forceinline__ void conv_split_pair_resident(
         const float4* const pf = sp.pmF + (size_t)q * kBinsB;
         using B16 = fft::Butterfly<16, false>;
         using B16i = fft::Butterfly<16, true>;
-        cf tw2[15];                                                   // the last pass's powers: W4096^(r t)
-        fft::powers_of<16>(tw[ft], tw2);
+        // the last pass's powers, W4096^(r t): kept (30 registers), or — LEAN_TW, the 128-register build — re-formed from their
+        // base where they are used (the same powers_of: the same values)
+        cf tw2_kept[LEAN_TW ? 1 : 15];
+        const cf tw2_base = tw[ft];
+        if constexpr (!LEAN_TW) fft::powers_of<16>(tw2_base, tw2_kept);
+        auto tw2_of = [&](cf (&w)[15]) {
+            if constexpr (LEAN_TW) {
+                cf b = tw2_base;
+                asm volatile("" : "+v"(b.x), "+v"(b.y));             // pinned to the pass
+                fft::powers_of<16>(b, w);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) w[r] = tw2_kept[r];
+            }
+        };
         // LDS positions are formed where they are used, from an opaque copy of the thread index: as loop invariants they
         // would be kept (and spilled) across both halves of a transform
         auto opaque_t = [&]() -> unsigned { unsigned v = (unsigned)ft; asm volatile("" : "+v"(v)); return v; };
@@ -2379,24 +2392,29 @@ __device__ __forceinline__ void conv_split_pair_resident(
         auto rd_of = [](unsigned t) -> unsigned { return t + (t >> 4); };                  // linear reads: Pad(t + 256 r) = rd + 272 r
         auto w1_of = [](unsigned t) -> unsigned { const unsigned b1 = (t >> 4) * 256u + (t & 15u); return b1 + (b1 >> 4); };   // pass-1 writes: + 17 r
         auto tw1row_of = [&](unsigned t) -> const cf* { return tw1 + (t & 15u) * 15u; };
-        // window of buffer nb: blocks k-7 .. k — from the input buffers where they lie inside the launch, else the ring
-        auto load_window = [&](int nb, cf (&z)[16]) {
+        // PART 0: the seven older blocks' first halves + the newest block (16 requests); PART 1: the rest (16 requests) — the
+        // requests of one window go out in two intervals: thirty-two in one made that interval the period's longest
+        auto load_window = [&](auto part_tag, int nb, cf (&z)[16]) {
+            constexpr int PART = decltype(part_tag)::value;
             const int head = (head0 + nb) & (kSlots - 1);
             int fo = ft;
             asm volatile("" : "+v"(fo));                              // (addresses formed here, not hoisted and spilled)
-            const float* const cur = in_slot(nb);
-            z[14] = mk(cur[ca + fo], cur[cb_ + fo]);
-            z[15] = mk(cur[ca + fo + kThreads], cur[cb_ + fo + kThreads]);
+            if constexpr (PART == 0) {
+                const float* const cur = in_slot(nb);
+                z[14] = mk(cur[ca + fo], cur[cb_ + fo]);
+                z[15] = mk(cur[ca + fo + kThreads], cur[cb_ + fo + kThreads]);
+            }
+            constexpr int BL0 = PART == 0 ? 4 : 0, BL1 = PART == 0 ? 7 : 4;       // blocks k-7+bl
             if (nb >= kSlots - 1) {
 #pragma unroll
-                for (int bl = 0; bl < 7; ++bl) {
+                for (int bl = BL0; bl < BL1; ++bl) {
                     const float* const src = in_slot(nb - (7 - bl));
                     z[2 * bl] = mk(src[ca + fo], src[cb_ + fo]);
                     z[2 * bl + 1] = mk(src[ca + fo + kThreads], src[cb_ + fo + kThreads]);
                 }
             } else {
 #pragma unroll
-                for (int bl = 0; bl < 7; ++bl) {                      // block k-7+bl = buffer nb-7+bl (uniform branch)
+                for (int bl = BL0; bl < BL1; ++bl) {                  // block k-7+bl = buffer nb-7+bl (uniform branch)
                     if (nb - 7 + bl >= 0) {
                         const float* const src = in_slot(nb - (7 - bl));
                         z[2 * bl] = mk(src[ca + fo], src[cb_ + fo]);
@@ -2410,8 +2428,12 @@ __device__ __forceinline__ void conv_split_pair_resident(
             }
         };
         cf z[16], zn[16];
-        float4 c[16];
-        // first half of a transform: forward passes, partner exchange, product, first inverse butterfly (six barriers)
+        // The requests ride on the lighter steps (every instruction of a step costs the wave about a dozen clocks beside two
+        // others on its SIMD: thirty-two requests in one interval made it the period's longest), the wait for the carry's stores
+        // stands in the idle interval.  (Measured and not kept, profiles/r06_batch12_stamps.txt: steps cut as read + twiddle |
+        // butterfly + write, so that no step is a bare write — 5.08 against 5.01 us per buffer.)
+        // first half of a transform (period nb):   pass 0, write | read, twiddle, pass 1 | write (+ spectra 0-7) |
+        //                                          read, twiddle (+ spectra 8-15), pass 2 | partner write | partner read, product, inverse pass 0
         auto first_half = [&](int nb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = zn[r];
@@ -2437,62 +2459,76 @@ __device__ __forceinline__ void conv_split_pair_resident(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16::out_slot(r)];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            {
+            float4 clo[8], chi[8];                                    // the far spectra (LEAN_TW: asked for later, registers)
+            if constexpr (!LEAN_TW) {
+                __builtin_amdgcn_sched_barrier(0);
                 int fo = ft;
                 asm volatile("" : "+v"(fo));
-                load_spectra<kNB, 16>(c, pf, fo);                     // needed three intervals from now
+                load_spectra_part<kNB, 16, 0, 8>(clo, pf, fo);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             GAB_PAIRBAR(nb, 2);                                          // 3
             {
                 const unsigned rd = rd_of(opaque_t());
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
             }
-#pragma unroll
-            for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw2[r - 1]);
-            B16::run(z);
             {
+                cf tw2[15];
+                tw2_of(tw2);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw2[r - 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                if constexpr (LEAN_TW) load_spectra_part<kNB, 16, 0, 8>(clo, pf, fo);      // (behind the twiddle multiply: its powers are dead)
+                else load_spectra_part<kNB, 16, 8, 16>(chi, pf, fo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            B16::run(z);
+            GAB_PAIRBAR(nb, 3);                                          // 4
+            {
+                const unsigned t = opaque_t();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[t + 256u * r] = z[B16::out_slot(r)];   // Z[t + 256 r]: the partner exchange, raw
+            }
+            if constexpr (LEAN_TW) {
+                __builtin_amdgcn_sched_barrier(0);
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_spectra_part<kNB, 16, 8, 16>(chi, pf, fo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            GAB_PAIRBAR(nb, 4);                                          // 5
+            {
+                // the thread's own bins back in order, and Z[(N - k) mod N], k = t + 256 r: one base and constant offsets for
+                // r >= 1 (N - k > 0 there); bin k = t alone wraps
                 cf o[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = z[B16::out_slot(r)];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = o[r];            // z[r] = Z[t + 256 r]
-            }
-            GAB_PAIRBAR(nb, 3);                                          // 4
-            {
-                const unsigned t = opaque_t();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) img[t + 256u * r] = z[r];    // partner exchange, raw
-            }
-            GAB_PAIRBAR(nb, 4);                                          // 5
-            {
-                // Z[(N - k) mod N], k = t + 256 r: one base and constant offsets for r >= 1 (N - k > 0 there); bin k = t alone wraps
                 const unsigned t = opaque_t();
                 const cf* const pb = img + (kNB - 256 * 15) - t;      // pb[256 (15 - r)] = img[N - t - 256 r]
                 cf zp[8];
                 zp[0] = img[(kNB - t) & (kNB - 1)];
 #pragma unroll
                 for (int r = 1; r < 8; ++r) zp[r] = pb[256 * (15 - r)];
-                float4 ch[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) ch[r] = c[r];
-                spectral_product_part<kNB, 16, 0, 8>(z, zp, ch, ft);
+                spectral_product_part<kNB, 16, 0, 8>(z, zp, clo, ft);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) zp[r] = pb[256 * (7 - r)];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) ch[r] = c[8 + r];
-                spectral_product_part<kNB, 16, 8, 16>(z, zp, ch, ft);
+                spectral_product_part<kNB, 16, 8, 16>(z, zp, chi, ft);
             }
             B16i::run(z);
             GAB_PAIRBAR(nb, 5);                                          // 6
         };
-        // second half: the inverse's exchanges and its last pass; the window of this group's NEXT transform is asked for
-        // in the first interval (the transform's own registers are busy until the last pass)
+        // second half (period nb + 1):   (half of the next window's requests) | write | read, twiddle, pass 1 |
+        //                                write (+ the other half) | read, twiddle, last pass (4 of 16), carry out | (the carry's stores leave)
         auto second_half = [&](int period, int nb_done, int nb_next) {
             if (nb_next >= 0) {
-                load_window(nb_next, zn);
+                load_window(std::integral_constant<int, 0>{}, nb_next, zn);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zn[r] = mk(0.0f, 0.0f);  // (no value survives from the last window: registers)
@@ -2519,13 +2555,20 @@ __device__ __forceinline__ void conv_split_pair_resident(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16i::out_slot(r)];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nb_next >= 0) load_window(std::integral_constant<int, 1>{}, nb_next, zn);      // the window's other half, beside the light write
+            __builtin_amdgcn_sched_barrier(0);
             GAB_PAIRBAR(period, 3);                                          // 4
             if (nb_done >= 0) {
                 const unsigned rd = rd_of(opaque_t());
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+                {
+                    cf tw2[15];
+                    tw2_of(tw2);
 #pragma unroll
-                for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw2[r - 1]);
+                    for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw2[r - 1]);
+                }
                 cf x12, x13, x14, x15;
                 B16i::run_last4(z, x12, x13, x14, x15);
                 const int head = (head0 + nb_done) & (kSlots - 1);
@@ -2535,11 +2578,11 @@ __device__ __forceinline__ void conv_split_pair_resident(
                 c1[ft + kThreads] = x13;
                 c2[ft] = x14;
                 c2[ft + kThreads] = x15;
-                // the inverse wave of this pair asks for block k+1's share behind the next closing barrier: the stores
-                // must have left this wave by then
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             GAB_PAIRBAR(period, 4);                                          // 5
+            // the inverse wave of this pair asks for block k+1's share behind the period's closing barrier: the stores must
+            // have left this wave by then (waited for HERE, in the group's idle interval, not on its last pass)
+            if (nb_done >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GAB_PAIRBAR(period, 5);                                          // 6
         };
         const int first = (g - head0) & 1;                             // this group's first window
@@ -2548,7 +2591,8 @@ __device__ __forceinline__ void conv_split_pair_resident(
             second_half(0, -1, 1 < n_buffers ? 1 : -1);                   // period 0: nothing to finish, window 1 asked for
             nb = 1;
         } else if (n_buffers > 0) {
-            load_window(0, zn);
+            load_window(std::integral_constant<int, 0>{}, 0, zn);
+            load_window(std::integral_constant<int, 1>{}, 0, zn);
         }
         for (;;) {                                                     // nb: a period in which a transform of this group starts
             if (nb > n_buffers) break;
@@ -2576,9 +2620,11 @@ __device__ __forceinline__ void conv_split_pair_resident(
                 constexpr int R0 = decltype(r0_tag)::value;
                 cf zp[4];
                 float4 ch[4];
+                int lo = lane;
+                asm volatile("" : "+v"(lo));                          // (LDS positions formed here: as loop invariants they were kept and spilled)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * (R0 + r))) & (kNA - 1))];
-                load_spectra_part<kNA, 16, R0, R0 + 4>(ch, sp_lds, lane);
+                for (int r = 0; r < 4; ++r) zp[r] = img[PadA16::at((kNA - (lo + 64 * (R0 + r))) & (kNA - 1))];
+                load_spectra_part<kNA, 16, R0, R0 + 4>(ch, sp_lds, lo);
                 spectral_product_part<kNA, 16, R0, R0 + 4>(v, zp, ch, lane);
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -2718,8 +2764,21 @@ __global__ __launch_bounds__(kB6Threads, 3) void conv_split_batch6_kernel(
     __shared__ __attribute__((aligned(16))) cf lds[kB6Lds];
     HardwareBarrier sync;
     // the pair: neighbours in one XCD, their output lines meet in its L2
-    conv_split_pair_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds, (int)threadIdx.x,
-                             xcd_contiguous(blockIdx.x, gridDim.x), sync, (int)(threadIdx.x >> 6));
+    conv_split_pair_resident<false>(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds, (int)threadIdx.x,
+                                    xcd_contiguous(blockIdx.x, gridDim.x), sync, (int)(threadIdx.x >> 6));
+}
+
+// The same at FOUR waves per SIMD (128 registers: the last pass's twiddle powers re-formed where they are used), so that two of
+// these workgroups — 2, 2, 1, 1 waves on the SIMDs each — fit one compute unit.
+// (Its LDS is DYNAMIC: with the 79 KB as a static array the compiler knows that two workgroups = three waves per SIMD on average
+// fit a compute unit and hands out 168 registers whatever the launch bounds say; the SIMDs that get FOUR of the twelve waves need 128.)
+__global__ __launch_bounds__(kB6Threads, 4) void conv_split_batch6r_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
+    extern __shared__ __attribute__((aligned(16))) cf lds_dyn[];
+    HardwareBarrier sync;
+    conv_split_pair_resident<true>(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds_dyn, (int)threadIdx.x,
+                                   xcd_contiguous(blockIdx.x, gridDim.x), sync, (int)(threadIdx.x >> 6));
 }
 
 // ---- two pairs per workgroup again, each with a barrier of its own (round 6) -------------------------------------------------------
@@ -2738,8 +2797,8 @@ __global__ __launch_bounds__(kB26Threads) void conv_split_batch2x6_kernel(
     __syncthreads();
     const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) >= 6 ? 1 : 0);
     CounterBarrier sync{counters + 32 * h, 0u, false};
-    conv_split_pair_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds + h * kB6Lds, (int)threadIdx.x - h * kB6Threads,
-                             2 * xcd_contiguous(blockIdx.x, gridDim.x) + h, sync, (int)(threadIdx.x >> 6));
+    conv_split_pair_resident<false>(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds + h * kB6Lds, (int)threadIdx.x - h * kB6Threads,
+                                    2 * xcd_contiguous(blockIdx.x, gridDim.x) + h, sync, (int)(threadIdx.x >> 6));
 }
 
 #endif   // GAB_ABLATE
@@ -4088,6 +4147,16 @@ int gab_conv_process_batch(gab_conv_plan* p, const float* d_in, float* d_out, in
                         gab::conv_split_batch2x6_kernel<<<dim3(p->tracks / 4), dim3(gab::kB26Threads), 0, s>>>(
                             d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
                         rc = gab::launch_status("conv_split_batch2x6_kernel");
+                    } else if (waves == 64) {                   // six waves per pair at four waves per SIMD (128 registers)
+                        static bool dyn_set = false;
+                        if (!dyn_set) {
+                            GAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gab::conv_split_batch6r_kernel),
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(gab::kB6Lds * sizeof(gab::fft::cf))));
+                            dyn_set = true;
+                        }
+                        gab::conv_split_batch6r_kernel<<<dim3(p->tracks / 2), dim3(gab::kB6Threads), gab::kB6Lds * sizeof(gab::fft::cf), s>>>(
+                            d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
+                        rc = gab::launch_status("conv_split_batch6r_kernel");
                     } else if (waves == 6) {
                         gab::conv_split_batch6_kernel<<<dim3(p->tracks / 2), dim3(gab::kB6Threads), 0, s>>>(
                             d_in + done * step, d_out + done * step, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, n);
