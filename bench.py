@@ -706,6 +706,8 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     rplan.launch_round_trip(rt_args)
     res["paced_10p667ms"]["keep_warm"] = dict(paced_calls(), what="gab_conv_round_trip_keep_warm(plan, 1): every call ends by kicking a resident "
                                               "launch of eight sleeping waves (one per XCD), which ends by itself about 0.1 s (eight buffer periods) after the last call")
+    # where the eight waves landed (gab_keep_warm_placement): a run in which they buy nothing classifies itself
+    res["paced_10p667ms"]["keep_warm"]["placement"] = gab.ops.placement_summary(rplan.round_trip_keep_warm_placement())
     rplan.round_trip_keep_warm(False)
     rplan.close()
     return res
