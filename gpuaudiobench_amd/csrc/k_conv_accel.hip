@@ -634,6 +634,7 @@ constexpr size_t kRtUploadPiece = (size_t(4) << 20) - 256;   // bytes per engine
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
 constexpr int kRtMaxGroups = 40;
+constexpr int kEngineWaves = 8;                    // gab_conv_engine_start: conv_split_engine12_kernel (12) or conv_split_engine_kernel (8)
 constexpr int kBatchWaves = 12;                    // gab_conv_process_batch on a split plan: conv_split_batch12_kernel (12) or conv_split_batch_kernel (8)
 constexpr size_t kBatchChunk = 256;                // buffers per conv_split_batch_kernel launch at most (see gab_conv_process_batch)
 struct ConvRoundTrip {
@@ -2810,6 +2811,668 @@ __global__ __launch_bounds__(kB12Threads) void conv_split_batch12_kernel(
     conv_split_batch12_resident(in, out, hist, pmA, sp, tw, T, head0, n_buffers, lds);
 }
 
+// ---- the doorbell-fed engine on the twelve-wave period code (round 6) ----------------------------------------------------------
+// conv_split_batch12_resident's roles behind conv_split_engine_resident's doorbell: the same gate (every wave asks it once per
+// period, in step), bursts that start cold and end with a drain period, ring slots, system-scope input loads, write-through
+// outputs, per-wave progress words.  A far group's transform spans two periods, so a transform begun in a burst's LAST period is
+// finished in the burst's drain period; the window of a group's next turn is asked for a period ahead where that buffer is
+// published (block k-1 then comes from the input ring), else at the turn itself (block k-1 from the history ring).
+#ifdef GAB_ABLATE
+// diagnostic bit 64: every wave's lane 0 stamps its ARRIVAL at each barrier of periods 4000 and 4001 (tools/stamp_engine12.py)
+#define GAB_E12BAR(i)                                                                                                 \
+    do {                                                                                                              \
+        if (GAB_SDBG(64) && (nb == 4000 || nb == 4001) && lane == 0)                                                  \
+            g_split_stamps[(((size_t)blockIdx.x * 12 + w) * 2 + (nb - 4000)) * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        __syncthreads();                                                                                              \
+    } while (0)
+#else
+#define GAB_E12BAR(i) __syncthreads()
+#endif
+__device__ __forceinline__ void conv_split_engine12_resident(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, const ConvSplit& sp, const cf* __restrict__ tw, int T, int head0,
+    const ConvEngine& eng, cf* __restrict__ lds, unsigned* __restrict__ s_door) {
+    constexpr bool ENGINE = true;
+    constexpr int n_buffers = 0;
+    (void)ENGINE; (void)n_buffers;
+    cf* const far_img = lds + 6 * kWaveImg;                           // [group][kLdsHalf]
+    float4* const spec = reinterpret_cast<float4*>(far_img + 2 * kLdsHalf);   // [A p0 | A p1 | A2 p0 | A2 p1][513]
+    cf* const tw1 = reinterpret_cast<cf*>(spec + 4 * kBinsA);          // [16][15]: the middle pass's twiddle powers
+    const int tid = threadIdx.x;
+    const int d = xcd_contiguous(blockIdx.x, gridDim.x);
+    const size_t step = (size_t)T * kB;
+    {
+        const float4* const gA = pmA + (size_t)(2 * d) * kBinsA;
+        const float4* const gA2 = sp.pmA2 + (size_t)(2 * d) * kBinsA;
+        for (int i = tid; i < 2 * kBinsA; i += kB12Threads) { spec[i] = gA[i]; spec[2 * kBinsA + i] = gA2[i]; }
+        if (tid < 16) {
+            cf pw[15];
+            fft::powers_of<16>(tw[tid * (fft::kTwiddleN / 256)], pw);
+#pragma unroll
+            for (int r = 0; r < 15; ++r) tw1[tid * 15 + r] = pw[r];
+        }
+    }
+    constexpr int kPoller = 2 * 64;                                   // lane 0 of the first inverse wave
+    // the doorbell as this workgroup may read it: workgroup 0 asks the host and passes the answer on, the others ask the relay
+    auto read_door = [&]() -> unsigned {
+        if (blockIdx.x == 0) {
+            const unsigned v = __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(eng.relay, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        }
+        return __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (tid == 0) {
+        s_door[2] = 0;
+        // has the launch become resident?  The first and the last workgroup to begin say so in host words: a wait that
+        // runs out can then tell "never started" (something ahead of it on its hardware queue) and "some workgroups are
+        // kept out" (waves of another launch hold registers or LDS on their compute units) from a silent producer
+        const unsigned before = __hip_atomic_fetch_add(eng.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == 0) __hip_atomic_store(&eng.resident[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (before + 1 == gridDim.x) __hip_atomic_store(&eng.resident[1], gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned rb = (unsigned)lane + ((unsigned)lane >> 4);      // Pad(lane + 64 r) = rb + 68 r
+    // The aggregator — the first inverse wave of workgroup 1 (workgroup 0 where there is only one) — takes every inverse wave's count
+    // of finished buffers (8 per lane, sc1 loads) and writes the minimum into `completed` (pinned host word), from the period loop
+    // and from the idle loop below.  Not workgroup 0: that one's idle loop reads the doorbell over the link, two microseconds a look,
+    // and a count that waits behind such a look reaches the host that much later.
+    const bool aggregator = blockIdx.x == (gridDim.x > 1 ? 1u : 0u);
+    unsigned reported = 0;                                            // (meaningful in that wave only)
+    auto aggregate_request = [&](u4& a, u4& b) {
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc(eng.progress, 0, (int)(8u * gridDim.x), 0x00020000);
+        a = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane, 0, 16);          // sc1; beyond the end: zeros dropped below
+        b = __builtin_amdgcn_raw_buffer_load_b128(srd, 32u * (unsigned)lane + 16u, 0, 16);
+    };
+    auto aggregate_report = [&](const u4& a, const u4& b) {
+        const unsigned words = 2u * gridDim.x;                        // lanes beyond the array read zeros: mask them out
+        auto pick = [&](unsigned v, unsigned idx) { return idx < words ? v : 0xffffffffu; };
+        unsigned m = min(min(min(pick(a[0], 8u * lane), pick(a[1], 8u * lane + 1)), min(pick(a[2], 8u * lane + 2), pick(a[3], 8u * lane + 3))),
+                         min(min(pick(b[0], 8u * lane + 4), pick(b[1], 8u * lane + 5)), min(pick(b[2], 8u * lane + 6), pick(b[3], 8u * lane + 7))));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+        if (m != reported) {
+            reported = m;
+            if (lane == 0) __hip_atomic_store(eng.completed, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    // How many buffers may be touched, asked by EVERY wave — at the top of period nb of a burst (same answer in all of them:
+    // it is read from LDS, written before the previous period's closing barrier), and with idle = true between bursts.
+    // Batch launches: n_buffers.  The engine's doorbell word: bits 0-29 buffers published so far, bit 31 STOP (no more will
+    // come), bit 30 FLUSH (finish what is published without waiting for more).  A period runs buffer nb when buffer nb + 1
+    // is there too (its operands are requested one period ahead) — or, on STOP or FLUSH, when nb is the last one published:
+    // that period requests nothing, the burst ends behind it with a drain period, and the workgroup idles here until the
+    // doorbell moves (the next burst starts cold: a real-time caller with ONE buffer in flight rings FLUSH with every
+    // buffer).  Returns the count published (> nb), or -1: the stop rung with nothing pending — the launch ends.
+    auto gate = [&](int nb, bool idle) -> int {
+        {
+            if (idle && __builtin_amdgcn_readfirstlane(s_door[2]) != 0) return -1;   // the doorbell ran out of time in this burst: no further wait
+            bool look = !idle;                                        // an idle gate asks first: the word in LDS is the one the last burst ended on
+            for (;;) {
+                if (look) {
+                    // (the same word in every lane: said so, or every test on it becomes an exec-masked region — the far
+                    // role's request burst under a divergent branch took 2.4 instead of 1.4 us of its barrier interval)
+                    const unsigned D = __builtin_amdgcn_readfirstlane(s_door[nb & 1]);
+                    const int pub = (int)(D & 0x3fffffffu);
+                    const bool stop = (D >> 31) != 0, flush = ((D >> 30) & 1u) != 0;
+                    if (pub >= nb + 2 || ((stop || flush) && pub >= nb + 1)) return pub;
+                    if (stop) return -1;                              // nothing more will come
+                }
+                look = true;
+                __syncthreads();                                      // every wave has read the word
+                if (w == 2) {                                         // the first inverse wave polls (lane 0 asks; workgroup 0's also aggregates)
+                    unsigned v = 0;
+                    int tries = 0;
+                    const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        u4 pa, pb;
+                        if (aggregator && !GAB_EABL(1)) aggregate_request(pa, pb);
+                        unsigned mine = 0;
+                        if (lane == 0) mine = read_door();
+                        v = __builtin_amdgcn_readfirstlane(mine);
+                        if (aggregator && !GAB_EABL(1)) aggregate_report(pa, pb);
+                        const int p2 = (int)(v & 0x3fffffffu);
+                        if (p2 >= nb + 2 || (v >> 31) || (((v >> 30) & 1u) && p2 >= nb + 1)) break;
+                        if ((++tries & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t_poll > eng.idle_ticks) {   // the producer is gone: stop here, say so
+                            if (lane == 0) {
+                                __hip_atomic_store(eng.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                s_door[2] = 1;
+                            }
+                            v = 0x80000000u | (unsigned)(p2 < nb ? p2 : nb);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(6);                      // (~0.2 us between looks: with 20, a quarter of a microsecond more from doorbell to count)
+                    }
+                    if (lane == 0) s_door[nb & 1] = v;
+                }
+                __syncthreads();
+            }
+        }
+    };
+    // buffer nb lives in slot nb % ring of the engine's rings (a batch launch: buffer nb itself); callers walk the slots
+    // with next_slot() instead of dividing
+    auto in_slot = [&](int slot) -> const float* { return in + (size_t)slot * step; };
+    auto next_slot = [&](int slot) -> int { return (ENGINE && slot + 1 == eng.ring) ? 0 : slot + 1; };
+    // The engine's input ring is rewritten while the launch runs (by copy engines): its loads are system-scope loads,
+    // answered by memory and never by a line an L1 or an L2 kept.  The rings are ORDINARY device memory (round 4, measured
+    // at 1024 channels: fine-grained rings read by non-temporal loads 6.85 us per buffer, ordinary rings read by
+    // system- or agent-scope loads 6.09-6.13, by plain loads — which may be stale — 6.2-6.3).
+    auto ld = [](const float* p) -> float {
+        if constexpr (ENGINE)
+            return GAB_EABL(4)     ? *p
+                   : GAB_EABL(256) ? __builtin_nontemporal_load(p)
+                                   : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc0 sc1
+        else return *p;
+    };
+
+    auto idle_period = [&]() { for (int i = 0; i < kBatchBarriers; ++i) __syncthreads(); };
+
+    if (w >= 4) {
+        // ---- far waves: group g turns pair g of the duo, one transform per two periods
+        const int g = __builtin_amdgcn_readfirstlane((w - 4) >> 2);
+        const int ft = (tid - kThreads) & (kThreads - 1);
+        cf* const img = far_img + g * kLdsHalf;
+        const int q = 2 * d + g;
+        const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const cg = sp.carry + (size_t)q * kCarrySlots * kB;
+        const size_t ca = (size_t)(2 * q) * kB, cb_ = ca + kB;
+        const float4* const pf = sp.pmF + (size_t)q * kBinsB;
+        using B16 = fft::Butterfly<16, false>;
+        using B16i = fft::Butterfly<16, true>;
+        // the last pass's powers, W4096^(r t), are re-formed from their base where they are used (the same powers_of: the same
+        // values; kept in 30 registers, as the batch launch keeps them, the engine's waves spilled)
+        const cf tw2_base = tw[ft];
+        auto tw2_of = [&](cf (&w)[15]) {
+            cf b = tw2_base;
+            asm volatile("" : "+v"(b.x), "+v"(b.y));                 // pinned to the pass
+            fft::powers_of<16>(b, w);
+        };
+        // LDS positions are formed where they are used, from an opaque copy of the thread index: as loop invariants they
+        // would be kept (and spilled) across both halves of a transform
+        auto opaque_t = [&]() -> unsigned { unsigned v = (unsigned)ft; asm volatile("" : "+v"(v)); return v; };
+        auto w0_of = [](unsigned t) -> unsigned { return t * 17u; };                       // pass-0 writes: Pad(16 t + r) = 17 t + r
+        auto rd_of = [](unsigned t) -> unsigned { return t + (t >> 4); };                  // linear reads: Pad(t + 256 r) = rd + 272 r
+        auto w1_of = [](unsigned t) -> unsigned { const unsigned b1 = (t >> 4) * 256u + (t & 15u); return b1 + (b1 >> 4); };   // pass-1 writes: + 17 r
+        auto tw1row_of = [&](unsigned t) -> const cf* { return tw1 + (t & 15u) * 15u; };
+        // window of buffer nb: blocks k-7 .. k — from the input buffers where they lie inside the launch, else the ring
+        // The window of buffer nb in two halves of sixteen requests (PART 0: blocks k-3 .. k, PART 1: blocks k-7 .. k-4).  The newest
+        // block comes from the input ring (system-scope loads: a copy engine wrote it); block k-1 from the input ring too where
+        // the window is asked for a period ahead (its copy in the history ring is being written in that very period), from the
+        // history ring at a COLD start (FIRST: the previous burst's last buffer; its ring slot may be the producer's again);
+        // everything older from the history ring, which the forward waves write every period.
+        auto load_window = [&](auto part_tag, auto first_tag, int nb, int slot, int slot_before, cf (&z)[16]) {
+            constexpr int PART = decltype(part_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int head = (head0 + nb) & (kSlots - 1);
+            int fo = ft;
+            asm volatile("" : "+v"(fo));                              // (addresses formed here, not hoisted and spilled)
+            if constexpr (PART == 0) {
+                const float* const cur = in_slot(slot);
+                z[14] = mk(ld(cur + ca + fo), ld(cur + cb_ + fo));
+                z[15] = mk(ld(cur + ca + fo + kThreads), ld(cur + cb_ + fo + kThreads));
+                if constexpr (!FIRST) {
+                    const float* const prv = in_slot(slot_before);
+                    z[12] = mk(ld(prv + ca + fo), ld(prv + cb_ + fo));
+                    z[13] = mk(ld(prv + ca + fo + kThreads), ld(prv + cb_ + fo + kThreads));
+                } else {
+                    const int s6 = ((head + kSlots - 1) & (kSlots - 1)) * kB;
+                    z[12] = hp[s6 + fo];
+                    z[13] = hp[s6 + kThreads + fo];
+                }
+#pragma unroll
+                for (int bl = 4; bl < 6; ++bl) {
+                    const int sb = ((head + 1 + bl) & (kSlots - 1)) * kB;
+                    z[2 * bl] = hp[sb + fo];
+                    z[2 * bl + 1] = hp[sb + kThreads + fo];
+                }
+            } else {
+#pragma unroll
+                for (int bl = 0; bl < 4; ++bl) {
+                    const int sb = ((head + 1 + bl) & (kSlots - 1)) * kB;
+                    z[2 * bl] = hp[sb + fo];
+                    z[2 * bl + 1] = hp[sb + kThreads + fo];
+                }
+            }
+        };
+        cf z[16], zn[16];
+        // The requests ride on the lighter steps (every instruction of a step costs the wave about a dozen clocks beside two
+        // others on its SIMD: thirty-two requests in one interval made it the period's longest), the wait for the carry's stores
+        // stands in the idle interval.  (Measured and not kept, profiles/r06_batch12_stamps.txt: steps cut as read + twiddle |
+        // butterfly + write, so that no step is a bare write — 5.08 against 5.01 us per buffer.)
+        // first half of a transform (period nb):   pass 0, write | read, twiddle, pass 1 | write (+ spectra 0-7) |
+        //                                          read, twiddle (+ spectra 8-15), pass 2 | partner write | partner read, product, inverse pass 0
+        auto first_half = [&](int nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = zn[r];
+            B16::run(z);
+            {
+                const unsigned w0 = w0_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w0 + r] = z[B16::out_slot(r)];
+            }
+            GAB_E12BAR(0);                                          // 1
+            {
+                const unsigned t = opaque_t(), rd = rd_of(t);
+                const cf* const tw1row = tw1row_of(t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw1row[r - 1]);
+            }
+            B16::run(z);
+            GAB_E12BAR(1);                                          // 2: every wave has read
+            {
+                const unsigned w1 = w1_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16::out_slot(r)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 clo[8], chi[8];                                    // the far spectra: bins r < 8 asked for here, r >= 8 an interval later
+            {
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_spectra_part<kNB, 16, 0, 8>(clo, pf, fo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_E12BAR(2);                                          // 3
+            {
+                const unsigned rd = rd_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+            }
+            {
+                cf tw2[15];
+                tw2_of(tw2);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmul(z[r], tw2[r - 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int fo = ft;
+                asm volatile("" : "+v"(fo));
+                load_spectra_part<kNB, 16, 8, 16>(chi, pf, fo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            B16::run(z);
+            GAB_E12BAR(3);                                          // 4
+            {
+                const unsigned t = opaque_t();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[t + 256u * r] = z[B16::out_slot(r)];   // Z[t + 256 r]: the partner exchange, raw
+            }
+            GAB_E12BAR(4);                                          // 5
+            {
+                // the thread's own bins back in order, and Z[(N - k) mod N], k = t + 256 r: one base and constant offsets for
+                // r >= 1 (N - k > 0 there); bin k = t alone wraps
+                cf o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = z[B16::out_slot(r)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = o[r];            // z[r] = Z[t + 256 r]
+                const unsigned t = opaque_t();
+                const cf* const pb = img + (kNB - 256 * 15) - t;      // pb[256 (15 - r)] = img[N - t - 256 r]
+                cf zp[8];
+                zp[0] = img[(kNB - t) & (kNB - 1)];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) zp[r] = pb[256 * (15 - r)];
+                spectral_product_part<kNB, 16, 0, 8>(z, zp, clo, ft);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = pb[256 * (7 - r)];
+                spectral_product_part<kNB, 16, 8, 16>(z, zp, chi, ft);
+            }
+            B16i::run(z);
+            GAB_E12BAR(5);                                          // 6
+        };
+        // second half (period nb + 1):   (half of the next window's requests) | write | read, twiddle, pass 1 |
+        //                                write (+ the other half) | read, twiddle, last pass (4 of 16), carry out | (the carry's stores leave)
+        auto second_half = [&](int period, int nb_done, int nb_next, int slot_next, int slot_now) {
+            const int nb = period;                                    // (the stamps' period)
+            (void)nb;
+            if (nb_next >= 0) {
+                load_window(std::integral_constant<int, 0>{}, std::false_type{}, nb_next, slot_next, slot_now, zn);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = mk(0.0f, 0.0f);  // (no value survives from the last window: registers)
+            }
+            GAB_E12BAR(0);                                          // 1
+            if (nb_done >= 0) {
+                const unsigned w0 = w0_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w0 + r] = z[B16i::out_slot(r)];
+            }
+            GAB_E12BAR(1);                                          // 2
+            if (nb_done >= 0) {
+                const unsigned t = opaque_t(), rd = rd_of(t);
+                const cf* const tw1row = tw1row_of(t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw1row[r - 1]);
+                B16i::run(z);
+            }
+            GAB_E12BAR(2);                                          // 3
+            if (nb_done >= 0) {
+                const unsigned w1 = w1_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[w1 + 17 * r] = z[B16i::out_slot(r)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nb_next >= 0) load_window(std::integral_constant<int, 1>{}, std::false_type{}, nb_next, slot_next, slot_now, zn);      // the window's other half, beside the light write
+            __builtin_amdgcn_sched_barrier(0);
+            GAB_E12BAR(3);                                          // 4
+            if (nb_done >= 0) {
+                const unsigned rd = rd_of(opaque_t());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = img[rd + 272 * r];
+                {
+                    cf tw2[15];
+                    tw2_of(tw2);
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) z[r] = fft::cmulc(z[r], tw2[r - 1]);
+                }
+                cf x12, x13, x14, x15;
+                B16i::run_last4(z, x12, x13, x14, x15);
+                const int head = (head0 + nb_done) & (kSlots - 1);
+                cf* const c1 = cg + ((head + 1) & (kCarrySlots - 1)) * kB;    // block k+1
+                cf* const c2 = cg + ((head + 2) & (kCarrySlots - 1)) * kB;    // block k+2
+                c1[ft] = x12;
+                c1[ft + kThreads] = x13;
+                c2[ft] = x14;
+                c2[ft + kThreads] = x15;
+            }
+            GAB_E12BAR(4);                                          // 5
+            // the inverse wave of this pair asks for block k+1's share behind the period's closing barrier: the stores must
+            // have left this wave by then (waited for HERE, in the group's idle interval, not on its last pass)
+            if (nb_done >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GAB_E12BAR(5);                                          // 6
+        };
+        // A group's state from period to period: a transform begun last period (to be finished in this one), a window asked for
+        // last period (for this one).  A burst starts cold; the group whose turn it is loads its window there and then.
+        bool in_flight = false, have_window = false;
+        int nb = 0, slot = 0;
+        for (;;) {                                                    // bursts
+            int avail = gate(nb, true);
+            if (nb >= avail) break;
+            for (;;) {                                                // the burst's periods
+                const bool mine = ((head0 + nb) & 1) == g;
+                if (mine) {
+                    if (!have_window) {
+                        load_window(std::integral_constant<int, 0>{}, std::true_type{}, nb, slot, 0, zn);
+                        load_window(std::integral_constant<int, 1>{}, std::true_type{}, nb, slot, 0, zn);
+                    }
+                    first_half(nb);
+                    in_flight = true;
+                    have_window = false;
+                } else {
+                    const bool can = nb + 1 < avail;                  // buffer nb + 1 is published: its window can be asked for
+                    second_half(nb, in_flight ? nb - 1 : -1, can ? nb + 1 : -1, next_slot(slot), slot);
+                    have_window = can;
+                    in_flight = false;
+                }
+                ++nb;
+                slot = next_slot(slot);
+                if (nb >= avail) break;                               // nothing was published for buffer nb: the burst ends here
+                avail = gate(nb, false);
+                if (nb >= avail) break;                               // (the doorbell ran out of time)
+            }
+            // the burst's drain period: a transform begun in the burst's last period is finished here
+            if (in_flight) second_half(nb, nb - 1, -1, 0, 0);
+            else idle_period();
+            in_flight = false;
+            have_window = false;
+        }
+    } else if (w < 2) {
+        // ---- forward waves: wave w holds pair w of the duo
+        const int q = 2 * d + w;
+        cf* const hp = reinterpret_cast<cf*>(hist) + (size_t)q * kSlots * kB;
+        cf* const img = lds + w * kWaveImg;                           // the transform's exchanges, then its spectrum
+        cf* const hand = lds + (2 + w) * kWaveImg;                    // A2 share, then the output spectrum for the inverse wave
+        const float4* const sa = spec + w * kBinsA;                   // taps [0,512)
+        const float4* const sa2 = spec + (2 + w) * kBinsA;            // taps [512,1024)
+        using WF = fft::WaveFFT1024<false>;
+        WF::Lean t;
+        WF::load_twiddles(t, tw, lane);
+        const size_t xoff = (size_t)(2 * q) * kB;                     // channel a of a buffer; channel b is kB further
+        cf z[16], prev[8], nxt[8];
+        // W = Z x spectra (from LDS) in halves of eight bins: partner values and spectra of a half live in registers at a time
+        auto product_from_image = [&](cf (&v)[16], const float4* sp_lds) {
+            {
+                cf zp[8];
+                float4 ch[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * r)) & (kNA - 1))];
+                load_spectra_part<kNA, 16, 0, 8>(ch, sp_lds, lane);
+                spectral_product_part<kNA, 16, 0, 8>(v, zp, ch, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                cf zp[8];
+                float4 ch[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) zp[r] = img[PadA16::at((kNA - (lane + 64 * (8 + r))) & (kNA - 1))];
+                load_spectra_part<kNA, 16, 8, 16>(ch, sp_lds, lane);
+                spectral_product_part<kNA, 16, 8, 16>(v, zp, ch, lane);
+            }
+        };
+        auto fwd_period = [&](int nb, int slot, int avail) {
+            // A2 share | hand-over + window + pass 0 | pass 1 | pass 2 | spectrum + A product | sum into the hand-over
+            const int head = (head0 + nb) & (kSlots - 1);
+            {
+                cf share[16];                                         // taps [512,1024): last period's spectrum x its spectra
+#pragma unroll
+                for (int r = 0; r < 16; ++r) share[r] = img[rb + 68 * r];
+                product_from_image(share, sa2);
+                GAB_E12BAR(0);                                   // barrier 1: the inverse wave has read the hand-over image
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = share[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { z[j] = prev[j]; z[8 + j] = nxt[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hp[head * kB + lane + 64 * j] = nxt[j];   // the history ring, every period (the last eight buffers are not known in advance)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = nxt[j];
+            if (nb + 1 < avail) {                                     // the next buffer's block: needed a period from now
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = in_slot(next_slot(slot)) + xoff + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(ld(xa + 64 * j), ld(xa + kB + 64 * j));
+            }
+            WF::run(z, img, t, lane, [&](int i) { GAB_E12BAR(1 + i); });   // barriers 2, 3 from inside
+            GAB_E12BAR(3);                                       // barrier 4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];     // the spectrum stays here for the next period
+            __builtin_amdgcn_wave_barrier();
+            product_from_image(z, sa);
+            GAB_E12BAR(4);                                       // barrier 5
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hand[rb + 68 * r] = fft::cadd(z[r], hand[rb + 68 * r]);   // A product + A2 share
+            GAB_E12BAR(5);                                       // barrier 6 closes the period
+        };
+        int nb = 0, slot = 0;                                         // the next buffer and its ring slot
+        bool primed = false;                                          // the image holds the spectrum of blocks [k-2 | k-1]
+        for (;;) {                                                    // bursts
+            int avail = gate(nb, true);
+            if (nb >= avail) break;
+            if (!primed) {
+                // the launch's first burst: the spectrum of the ring's blocks [k-2 | k-1] into the image (later bursts find it there)
+                const int s1 = ((head0 + kSlots - 1) & (kSlots - 1)) * kB, s2 = ((head0 + kSlots - 2) & (kSlots - 1)) * kB;
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = hp[s2 + lo + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) prev[j] = hp[s1 + lo + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[8 + j] = prev[j];
+                WF::run(z, img, t, lane, WF::NoHook());
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[rb + 68 * r] = z[r];
+                __builtin_amdgcn_wave_barrier();
+                primed = true;
+            }
+            {                                                         // the burst's first block
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const float* const xa = in_slot(slot) + xoff + lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mk(ld(xa + 64 * j), ld(xa + kB + 64 * j));
+            }
+            for (;;) {
+                fwd_period(nb, slot, avail);
+                ++nb;
+                slot = next_slot(slot);
+                if (nb >= avail) break;
+                avail = gate(nb, false);
+                if (nb >= avail) break;
+            }
+            idle_period();                                            // the burst's drain period
+        }
+    } else {
+        // ---- inverse waves: wave 2 + p turns the output spectrum of pair p into samples, one period later
+        const int pr = w - 2;
+        const cf* const hand = lds + (2 + pr) * kWaveImg;
+        cf* const img = lds + (4 + pr) * kWaveImg;                    // the transform's exchanges, then the output swap
+        const cf* const other = lds + (4 + (1 - pr)) * kWaveImg;
+        const cf* const cg = sp.carry + (size_t)(2 * d + pr) * kCarrySlots * kB;   // the far share comes through memory (agent-scope loads)
+        using WFi = fft::WaveFFT1024<true>;
+        WFi::Lean t;
+        WFi::load_twiddles(t, tw, lane);
+        int oslot = 0;                                                // of the next buffer to leave
+        int nb = 0, avail = 0, base = 0;                              // the period, buffers that may be touched, the burst's first buffer
+        bool boundary = true;                                         // between bursts (the launch's start is a boundary)
+        for (;;) {                                                    // periods base .. end of every burst; in a burst's last one only this role works (the drain)
+            if (boundary) {
+                avail = gate(nb, true);
+                if (nb >= avail) break;
+                base = nb;                                            // nothing to turn in a burst's first period
+                boundary = false;
+            } else if (nb < avail) {
+                avail = gate(nb, false);                              // (nb == avail: the drain period — the other roles ask nothing either)
+            }
+            const bool more = nb < avail;                         // the other roles work on buffer nb in this period
+            unsigned door_next = s_door[nb & 1];                  // (no per-period poll: the word as last seen)
+            u4 prog_a = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, prog_b = prog_a;
+            if constexpr (ENGINE) {
+                if (nb >= base + 2 && !GAB_EABL(1)) {
+                    // this wave's rows of buffer nb - 2 were stored a period ago: drained by now, so the wait is free,
+                    // and the count of finished buffers can go out (write-through, nobody waits for it)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)(nb - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == kPoller && eng.poll_every_period)      // asked now, needed at the period's end
+                    door_next = blockIdx.x == 0 ? __hip_atomic_load(eng.doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : __hip_atomic_load(eng.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (aggregator && pr == 0 && !GAB_EABL(1)) aggregate_request(prog_a, prog_b);
+            }
+            auto close_period = [&]() {                           // before the closing barrier
+                if constexpr (ENGINE) {
+                    if (aggregator && pr == 0 && !GAB_EABL(1)) aggregate_report(prog_a, prog_b);
+                    if (tid == kPoller) {
+                        s_door[(nb + 1) & 1] = door_next;
+                        if (blockIdx.x == 0 && eng.poll_every_period)
+                            __hip_atomic_store(eng.relay, door_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            };
+            bool idle_period = nb == base;                        // a burst's first period: nothing to turn yet
+#ifdef GAB_ABLATE
+            if (GAB_SDBG(1)) idle_period = true;                  // diagnostic builds: near role idle
+#endif
+            if (idle_period) {
+                for (int i = 0; i < kBatchBarriers - 1; ++i) __syncthreads();
+                close_period();
+                __syncthreads();
+            } else {
+                // One piece per barrier interval: hand-over read | pass 0 | pass 1 | pass 2 + far share | swap | stores
+                const int b = nb - 1;                             // the buffer whose spectrum was handed over last period
+                const int head = (head0 + b) & (kSlots - 1);
+                float* const outb = out + (size_t)(ENGINE ? oslot : b) * step;
+                oslot = next_slot(oslot);
+                cf z[16], y[8], park[8];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = hand[rb + 68 * r];    // the forward wave writes the next one in interval 6
+                {
+                    int lo = lane;
+                    asm volatile("" : "+v"(lo));
+                    const unsigned long long* const cy = reinterpret_cast<const unsigned long long*>(cg + (head & (kCarrySlots - 1)) * kB + lo);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned long long v = __hip_atomic_load(cy + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        park[j] = mk(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+                    }
+                }
+                GAB_E12BAR(0);                                    // barrier 1
+                WFi::run(z, img, t, lane, [&](int i) { GAB_E12BAR(1 + i); });   // barriers 2, 3 from inside
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
+                GAB_E12BAR(3);                                    // barrier 4
+                // the two pairs of a duo are four neighbouring channels: the waves swap halves through LDS
+                // so that each stores float4 pieces (pair 0 keeps samples lane + 64 j, j < 4, pair 1 j >= 4)
+                if (pr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[4 + j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) img[lane + 64 * j] = y[j];
+                }
+                GAB_E12BAR(4);                                    // barrier 5: the swapped halves are in LDS
+                {
+                    float* const o0 = outb + 4 * (size_t)d;
+                    auto put = [&](float* dst, float a, float b2, float c2, float d2) {
+                        if (ENGINE && !GAB_EABL(2)) {             // write-through: in memory before `completed` says so
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            const f4v val = {a, b2, c2, d2};
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+                        } else {
+                            *reinterpret_cast<float4*>(dst) = make_float4(a, b2, c2, d2);
+                        }
+                    };
+                    if (pr == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const cf theirs = other[lane + 64 * j];
+                            put(o0 + (size_t)T * (lane + 64 * j), y[j].x, y[j].y, theirs.x, theirs.y);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const cf theirs = other[lane + 64 * j];
+                            put(o0 + (size_t)T * (lane + 64 * (4 + j)), theirs.x, theirs.y, y[4 + j].x, y[4 + j].y);
+                        }
+                    }
+                }
+                close_period();
+                GAB_E12BAR(5);                                    // barrier 6 closes the period
+            }
+            if (!more) {
+                // the burst is through: this wave's last rows must be in memory before its count says so (the one wait for
+                // stores on this path: a workgroup that goes idle has nothing to hide it behind)
+                if (!GAB_EABL(1)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                boundary = true;
+                continue;
+            }
+            ++nb;
+        }
+    }
+}
+#undef GAB_E12BAR
+
+__global__ __launch_bounds__(kB12Threads) void conv_split_engine12_kernel(
+    const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
+    const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, ConvEngine eng) {
+    __shared__ __attribute__((aligned(16))) cf lds[kB12Lds];
+    __shared__ unsigned door[4];          // [0], [1] the doorbell as last seen, by period parity; [2] the engine has given up
+    conv_split_engine12_resident(in, out, hist, pmA, sp, tw, T, head0, eng, lds, door);
+}
+
 __global__ __launch_bounds__(kBatchThreads, 2) void conv_split_batch_kernel(
     const float* __restrict__ in, float* __restrict__ out, float* __restrict__ hist,
     const float4* __restrict__ pmA, ConvSplit sp, const cf* __restrict__ tw, int T, int head0, int n_buffers) {
@@ -3857,13 +4520,18 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
         if (!p || !d_in_ring || !d_out_ring) return gab::bad_arg("gab_conv_engine_start: null argument");
         if (!p->ir_set) return gab::bad_arg("gab_conv_engine_start: gab_conv_set_ir has not been called");
         if (p->eng_running) return gab::bad_arg("gab_conv_engine_start: the plan's engine is already running");
+        int waves = gab::kEngineWaves;                  // twelve waves per workgroup (three per SIMD, round 6) or eight: same bits
+#ifdef GAB_ABLATE
+        if (getenv("GAB_ENGINE_WAVES")) waves = atoi(getenv("GAB_ENGINE_WAVES"));      // diagnostic builds: A/B on one box
+#endif
         {
             // Every workgroup of the engine stays on the device until the stop and waits for words other workgroups write
             // (the relayed doorbell): all of them must be resident AT ONCE.  One fits per compute unit (151 KB of LDS).
             int dev = 0, cus = 0, per_cu = 0;
             GAB_HIP_CHECK(hipGetDevice(&dev));
             GAB_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            GAB_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gab::conv_split_engine_kernel, gab::kBatchThreads, 0));
+            if (waves == 12) GAB_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gab::conv_split_engine12_kernel, gab::kB12Threads, 0));
+            else GAB_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gab::conv_split_engine_kernel, gab::kBatchThreads, 0));
             const long room = (long)cus * per_cu;
             if ((long)(p->tracks / 4) > room)
                 return gab::bad_arg(("gab_conv_engine_start: the engine keeps one workgroup per four channels resident for the whole launch; this device holds " +
@@ -3902,8 +4570,12 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
 #endif
         gab::ConvEngine eng{p->eng_words, p->eng_done + prog_words - 1, p->eng_done, p->eng_words + 16, p->eng_words + 32, ring_buffers, poll,
                             p->eng_done + prog_words - 33, p->eng_words + 48, (unsigned long long)(p->eng_idle_seconds * 1e8)};
-        gab::conv_split_engine_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
-            p->eng_in, p->eng_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, eng);
+        if (waves == 12)
+            gab::conv_split_engine12_kernel<<<dim3(p->tracks / 4), dim3(gab::kB12Threads), 0, s>>>(
+                p->eng_in, p->eng_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, eng);
+        else
+            gab::conv_split_engine_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
+                p->eng_in, p->eng_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, eng);
         int rc = gab::launch_status("conv_split_engine_kernel");
         if (rc) return rc;
         p->eng_running = true;
