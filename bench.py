@@ -510,7 +510,7 @@ def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, b
     side.synchronize()
     eng_us = g0.elapsed_time(g1) * 1e3 / (passes * NB)
     res["one_buffer_per_doorbell"] = {
-        "entry": "gab_conv_engine_start / _feed / _stop: one resident launch (conv_split_engine_kernel), the host publishes ONE "
+        "entry": "gab_conv_engine_start / _feed / _stop: one resident launch (conv_split_engine12_kernel), the host publishes ONE "
                  "buffer per ring of the doorbell and keeps at most %d in flight" % ahead,
         "us_per_buffer": eng_us, "buffers_per_sec": 1e6 / eng_us, "alg_GBps": alg / eng_us / 1e3,
         "frac": alg / eng_us / 1e3 / HBM_PEAK_GBS, "buffers": passes * NB, "ahead": ahead, "ring_slots": NB,

@@ -634,7 +634,7 @@ constexpr size_t kRtUploadPiece = (size_t(4) << 20) - 256;   // bytes per engine
 constexpr int kRtCompletion = 2;                   // how gab_conv_round_trip observes the launch's end (see there)
 constexpr int kRtPollLimit = 1 << 21;              // x ~0.5 us of s_sleep: about a second, then the launch gives up
 constexpr int kRtMaxGroups = 40;
-constexpr int kEngineWaves = 8;                    // gab_conv_engine_start: conv_split_engine12_kernel (12) or conv_split_engine_kernel (8)
+constexpr int kEngineWaves = 12;                   // gab_conv_engine_start: conv_split_engine12_kernel (12) or conv_split_engine_kernel (8)
 constexpr int kBatchWaves = 12;                    // gab_conv_process_batch on a split plan: conv_split_batch12_kernel (12) or conv_split_batch_kernel (8)
 constexpr size_t kBatchChunk = 256;                // buffers per conv_split_batch_kernel launch at most (see gab_conv_process_batch)
 struct ConvRoundTrip {
@@ -978,6 +978,22 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #define GAB_ENGV 0
 #endif
 #define GAB_EABL(bit) ((GAB_ENGV & (bit)) != 0)
+// (experiments on the twelve-wave engine's output stores: GAB_ENGSTORE 1 "sc0 sc1", 2 "nt sc1", 3 "nt", 4 plain;
+// GAB_ENGWB: an L2 write-back by every inverse wave before its progress word)
+#ifndef GAB_ENGSTORE
+#define GAB_ENGSTORE 0
+#endif
+#if GAB_ENGSTORE == 1
+#define GAB_ENGSTORE_BITS "sc0 sc1"
+#elif GAB_ENGSTORE == 2
+#define GAB_ENGSTORE_BITS "nt sc1"
+#elif GAB_ENGSTORE == 3
+#define GAB_ENGSTORE_BITS "nt"
+#elif GAB_ENGSTORE == 4
+#define GAB_ENGSTORE_BITS ""
+#else
+#define GAB_ENGSTORE_BITS "sc1"
+#endif
 
 // ---- n buffers per launch (gab_conv_process_batch; bench.py's `value`) --------------------------------------------------
 // Round 5: the batch launch has this function to itself again.  Round 4 ran batch launch and engine from one template;
@@ -3362,6 +3378,12 @@ __device__ __forceinline__ void conv_split_engine12_resident(
                     // this wave's rows of buffer nb - 2 were stored a period ago: drained by now, so the wait is free,
                     // and the count of finished buffers can go out (write-through, nobody waits for it)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GAB_ENGWB
+                    asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef GAB_ENGWB8
+                    if (blockIdx.x < 8 && pr == 1) asm volatile("buffer_wbl2 sc1" ::: "memory");
+#endif
                     if (lane == 0) __hip_atomic_store(&eng.progress[2 * blockIdx.x + pr], (unsigned)(nb - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (tid == kPoller && eng.poll_every_period)      // asked now, needed at the period's end
@@ -3427,7 +3449,7 @@ __device__ __forceinline__ void conv_split_engine12_resident(
                         if (ENGINE && !GAB_EABL(2)) {             // write-through: in memory before `completed` says so
                             typedef float f4v __attribute__((ext_vector_type(4)));
                             const f4v val = {a, b2, c2, d2};
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off " GAB_ENGSTORE_BITS ::"v"(dst), "v"(val) : "memory");
                         } else {
                             *reinterpret_cast<float4*>(dst) = make_float4(a, b2, c2, d2);
                         }
@@ -4576,7 +4598,7 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
         else
             gab::conv_split_engine_kernel<<<dim3(p->tracks / 4), dim3(gab::kBatchThreads), 0, s>>>(
                 p->eng_in, p->eng_out, p->hist, p->pmA, sp, p->tw, p->tracks, p->head, eng);
-        int rc = gab::launch_status("conv_split_engine_kernel");
+        int rc = gab::launch_status(waves == 12 ? "conv_split_engine12_kernel" : "conv_split_engine_kernel");
         if (rc) return rc;
         p->eng_running = true;
         p->eng_published = 0;

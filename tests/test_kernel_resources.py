@@ -62,7 +62,8 @@ def test_headline_kernels_keep_their_occupancy(resources):
     for name in ("conv_split_batch_kernel", "conv_split_engine_kernel"):
         r = one(name)
         assert r["occupancy"] >= 2 and r["lds"] <= 160 * 1024, (name, r)     # one 512-thread workgroup per compute unit
-    r = one("conv_split_batch12_kernel")                                     # bench.py's `value`: twelve waves, three per SIMD
-    assert r["occupancy"] >= 3 and r["vgprs"] <= 168 and r["lds"] <= 160 * 1024, r
+    for name in ("conv_split_batch12_kernel", "conv_split_engine12_kernel"):   # bench.py's `value` and the doorbell engine: twelve waves, three per SIMD
+        r = one(name)
+        assert r["occupancy"] >= 3 and r["vgprs"] <= 168 and r["lds"] <= 160 * 1024, (name, r)
     assert one("17conv_batch_kernel")["vgprs"] <= 208                        # the looped body is the single-buffer launch's
     assert one("keep_warm_kernel")["vgprs"] <= 16                            # eight idle waves must fit beside anything but the engine

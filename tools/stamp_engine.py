@@ -1,7 +1,8 @@
 """Diagnostic build only (GAB_LIB_PATH=.../libgab_hip_ablate.so): the barrier timeline of tools/stamp_batch.py for the
-doorbell-fed ENGINE launch (period 4000 of a run whose buffers were all published before the launch looked: ~25 ms in, clocks settled)."""
+eight-wave doorbell-fed ENGINE launch (period 4000 of a run whose buffers were all published before the launch looked: ~25 ms in, clocks settled)."""
 import ctypes, os, sys
 os.environ.setdefault("GAB_CONV_SPLIT_DEBUG", "64")
+os.environ.setdefault("GAB_ENGINE_WAVES", "8")            # (the eight-wave engine: the product launches the twelve-wave one, tools/stamp_engine12.py)
 sys.path.insert(0, ".")
 import numpy as np, torch
 import gpuaudiobench_amd as gab
