@@ -51,7 +51,7 @@ def resources():
 def test_no_product_kernel_spills_to_scratch(resources):
     spilling = {k: v for k, v in resources.items() if v.get("scratch", 0) != 0}
     assert not spilling, spilling
-    assert len(resources) >= 60          # every .hip file was seen (66 kernels in round 6)
+    assert len(resources) >= 60          # every .hip file was seen (64 kernels in round 6; round 5's eight-wave launches are diagnostic-only now)
 
 
 def test_headline_kernels_keep_their_occupancy(resources):
@@ -59,9 +59,6 @@ def test_headline_kernels_keep_their_occupancy(resources):
         hits = [v for k, v in resources.items() if fragment in k]
         assert len(hits) == 1, (fragment, [k for k in resources if fragment in k])
         return hits[0]
-    for name in ("conv_split_batch_kernel", "conv_split_engine_kernel"):
-        r = one(name)
-        assert r["occupancy"] >= 2 and r["lds"] <= 160 * 1024, (name, r)     # one 512-thread workgroup per compute unit
     for name in ("conv_split_batch12_kernel", "conv_split_engine12_kernel"):   # bench.py's `value` and the doorbell engine: twelve waves, three per SIMD
         r = one(name)
         assert r["occupancy"] >= 3 and r["vgprs"] <= 168 and r["lds"] <= 160 * 1024, (name, r)
