@@ -980,7 +980,8 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #endif
 #define GAB_EABL(bit) ((GAB_ENGV & (bit)) != 0)
 // (experiments on the twelve-wave engine's output stores: GAB_ENGSTORE 1 "sc0 sc1", 2 "nt sc1", 3 "nt", 4 plain;
-// GAB_ENGWB: an L2 write-back by every inverse wave before its progress word)
+// GAB_ENGWB / GAB_ENGWB8: an L2 write-back by every inverse wave before its progress word / by one wave per XCD and period;
+// GAB_ENGPUSH: whole lines written through a second time — profiles/r06_engine12.md)
 #ifndef GAB_ENGSTORE
 #define GAB_ENGSTORE 0
 #endif
@@ -2078,6 +2079,22 @@ __device__ __forceinline__ void conv_split_engine12_resident(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) y[j] = fft::cadd(z[8 + j], park[j]);
                 GAB_E12BAR(3);                                    // barrier 4
+#ifdef GAB_ENGPUSH
+                // experiment (the cost alone, no protocol): this wave's share of the eight-workgroup line group's rows of the buffer
+                // stored FOUR periods ago is read back from L2 here and written through as whole 128-byte lines behind the stores
+                u4 pl[4] = {};
+                const bool push = nb >= base + 5;
+                char* pbase = nullptr;
+                if (push) {
+                    int ps = oslot - 4;
+                    if (ps < 0) ps += eng.ring;
+                    pbase = reinterpret_cast<char*>(out + (size_t)ps * step) + (size_t)(d >> 3) * 128 +
+                            (size_t)((((d & 7) * 2 + pr) * 32) + (lane >> 3)) * T * 4 + (lane & 7) * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pl[j]) : "v"(pbase + (size_t)8 * j * T * 4) : "memory");
+                }
+#endif
                 // the two pairs of a duo are four neighbouring channels: the waves swap halves through LDS
                 // so that each stores float4 pieces (pair 0 keeps samples lane + 64 j, j < 4, pair 1 j >= 4)
                 if (pr == 0) {
@@ -2113,6 +2130,14 @@ __device__ __forceinline__ void conv_split_engine12_resident(
                         }
                     }
                 }
+#ifdef GAB_ENGPUSH
+                if (push) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (loads and stores may come back out of order with each other)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pbase + (size_t)8 * j * T * 4), "v"(pl[j]) : "memory");
+                }
+#endif
                 close_period();
                 GAB_E12BAR(5);                                    // barrier 6 closes the period
             }
