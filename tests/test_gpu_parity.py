@@ -770,8 +770,12 @@ def test_conv_accel_engine_bursts_of_any_shape_walk_one_history(gab, orc, seed):
     a.set_ir(ir)
     b.set_ir(ir)
     N = 120
-    xs = [orc.noise(T * B, seed=7000 + 131 * seed + i) for i in range(N + 1)]
+    pre = 2 * seed - 1          # ordinary launches first, an ODD number: the far groups' turns then start on the other pair
+    xs = [orc.noise(T * B, seed=7000 + 131 * seed + i) for i in range(pre + N + 1)]
     want = [host(a.process(dev(x), mode=gab.CONV_STREAMING)) for x in xs]
+    for k in range(pre):
+        assert np.array_equal(bits(host(b.process(dev(xs[k]), mode=gab.CONV_STREAMING))), bits(want[k]))
+    xs, want = xs[pre:], want[pre:]
     side = torch.cuda.Stream()
     in_ring, out_ring = b.engine_start(R, stream=side)
     cur = torch.cuda.current_stream()
