@@ -921,8 +921,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_batch_kernel(
 // wave-held transform arrives at two of them from inside (WaveFFT1024's hook), so that each role does
 // about one transform pass per barrier interval.
 constexpr int kBatchBarriers = 6;
-constexpr int kBatchThreads = 2 * kThreads;
-constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;      // cf entries (151 KB)
 
 #ifdef GAB_ABLATE
 // diagnostic bit 64: in period 32 of a launch every wave's lane 0 stamps s_memrealtime (100 MHz) —

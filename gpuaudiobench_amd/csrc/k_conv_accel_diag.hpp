@@ -7,6 +7,9 @@
 // Same bits as the product's launches, all of them (the engine and batch tests run under GAB_*_WAVES in the diagnostic build).
 #pragma once
 
+constexpr int kBatchThreads = 2 * kThreads;                                            // round 5's workgroup: eight waves
+constexpr int kBatchLds = 6 * kWaveImg + 2 * kLdsHalf + 2 * kCarrySlots * kB;      // cf entries (151 KB)
+
 // ---- n buffers per launch (gab_conv_process_batch; bench.py's `value`) --------------------------------------------------
 // Round 5: the batch launch has this function to itself again.  Round 4 ran batch launch and engine from one template;
 // when the engine's period loop was wrapped in a loop over bursts (one buffer in flight, below), the SAME period code
@@ -59,7 +62,7 @@ __device__ __forceinline__ void conv_split_batch_resident(
         // run-time test on nb the engine's k-1 loads became conditional loads: a register merge behind them, i.e. a
         // wait for the whole request burst in the middle of the far chain — 2.3 instead of 1.4 us for that interval.)
         auto load_window = [&](auto first_tag, int nb, int slot, int slot_before, cf (&z)[16], float4 (&c)[16]) {
-            constexpr bool FIRST = decltype(first_tag)::value;
+            [[maybe_unused]] constexpr bool FIRST = decltype(first_tag)::value;
             const int head = (head0 + nb) & (kSlots - 1);
             const int q = 2 * d + (head & 1);
             const cf* const hp = reinterpret_cast<const cf*>(hist) + (size_t)q * kSlots * kB;
