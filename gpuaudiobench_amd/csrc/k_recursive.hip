@@ -1069,8 +1069,8 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                 static std::mutex slots_mu;
                 static unsigned next_slot = 0;
                 // 0: round 5's (8 lines per workgroup, staged input)   1, 2: no staging, 8 / 16 lines (r06: no faster — it was
-                // never the staging)   3, 4, 5: the lean kernel, 8 / 16 / 4 lines per workgroup: 15.5 / 19.6 / 14.0 us against
-                // 19.6 (profiles/r06_dwg.md); delay lines of 4 GiB and more per array: form 0
+                // never the staging)   3, 4, 5, 6, 7: the lean kernel, 8 / 16 / 4 / 2 / 1 lines per workgroup: 15.5 / 19.6 / 14.0 /
+                // 14.6 / 16.9 us against 19.6 (profiles/r06_dwg.md); delay lines of 4 GiB and more per array: form 0
                 int form = 5;
 #ifdef GAB_ABLATE
                 if (getenv("GAB_DWG_FORM")) form = atoi(getenv("GAB_DWG_FORM"));     // diagnostic builds: A/B on one box
@@ -1084,7 +1084,7 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                 if (sl.used && sl.last != s) GAB_HIP_CHECK(hipStreamWaitEvent(s, sl.busy, 0));
                 const unsigned long long line_bytes = 4ull * (unsigned long long)n_waveguides * (unsigned long long)max_len;
                 if (line_bytes >= 0xffffff00ull && form >= 3) form = 0;      // (a buffer resource's range is 32 bits)
-                const int UU = (form == 2 || form == 4) ? 16 : form == 5 ? 4 : U;
+                const int UU = (form == 2 || form == 4) ? 16 : form == 5 ? 4 : form == 6 ? 2 : form == 7 ? 1 : U;
                 dim3 grid((cells + 255) / 256, (n_waveguides + UU - 1) / UU);
 #define GAB_DWG_APPEND(UV, ST) gab::dwg_cells_append_kernel<UV, ST><<<grid, 256, 0, s>>>(wgs, d_fwd, d_bwd, d_in, ws, hits, mix_list, \
                                                                                 n_waveguides, n_mix, bufsize, max_len, slot)
@@ -1092,6 +1092,8 @@ int gab_dwg(const gab_waveguide_state* d_wg, float* d_fwd, float* d_bwd, const f
                                                                       bufsize, max_len, slot, (unsigned)line_bytes)
                 if (form == 5) GAB_DWG_LEAN(4);
 #ifdef GAB_ABLATE                                                // diagnostic builds: the forms that were measured and not kept
+                else if (form == 7) GAB_DWG_LEAN(1);
+                else if (form == 6) GAB_DWG_LEAN(2);
                 else if (form == 4) GAB_DWG_LEAN(16);
                 else if (form == 3) GAB_DWG_LEAN(U);
                 else if (form == 2) GAB_DWG_APPEND(16, false);
