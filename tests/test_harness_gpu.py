@@ -240,7 +240,7 @@ def test_driver_throughput_mode_reproduces_the_headline_through_the_harness():
     d = _json_of(r.stdout)
     assert d["roofline"]["algorithmic_bytes"] == 64 * 4 * 1024 * (2 * 512 + 2 * 4096)
     assert d["validation"]["passed"] is True and d["validation"]["max_error"] <= 1e-5
-    assert 0.3 < d["roofline"]["device_median_ms"] < 0.6          # 64 buffers in one launch: 0.34 ms warm
+    assert 0.25 < d["roofline"]["device_median_ms"] < 0.6         # 64 buffers in one launch: 0.31-0.33 ms warm (twelve-wave launch)
     assert d["roofline"]["frac"] > 0.6
     r = run_driver("--benchmark", "Conv1D_accel", "--convBatch", "0")
     assert r.returncode == 1 and "Error: --convBatch must be >= 1" in r.stdout
