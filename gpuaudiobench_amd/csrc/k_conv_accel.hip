@@ -3201,7 +3201,7 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
 #endif
         {
             // Every workgroup of the engine stays on the device until the stop and waits for words other workgroups write
-            // (the relayed doorbell): all of them must be resident AT ONCE.  One fits per compute unit (151 KB of LDS).
+            // (the relayed doorbell): all of them must be resident AT ONCE.  One fits per compute unit (153 KB of LDS).
             int dev = 0, cus = 0, per_cu = 0;
             GAB_HIP_CHECK(hipGetDevice(&dev));
             GAB_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -3217,10 +3217,11 @@ int gab_conv_engine_start(gab_conv_plan* p, int ring_buffers, float** d_in_ring,
                                      std::to_string(p->tracks) + " channels — shard the channels (one engine per device) or use gab_conv_process_batch").c_str());
         }
         if (int rc = gab_conv_engine_rings(p, ring_buffers, d_in_ring, d_out_ring)) return rc;
-        // The engine needs every compute unit WHOLE (two waves of 256 registers on each SIMD): with keep-warm waves on eight of
-        // them it cannot become resident until they have ended (first buffer 484 ms: profiles/r05_paced_keep_warm.txt).  It
-        // keeps the device awake itself.  The plan's own keep-warm goes; anybody else's is the caller's to end — said here,
-        // at the failing call, instead of a first buffer that answers half a second late.
+        // Round 5's engine needed every compute unit WHOLE (two waves of 256 registers on each SIMD): with keep-warm waves on
+        // eight of them it could not become resident until they had ended (first buffer 484 ms: profiles/r05_paced_keep_warm.txt).
+        // The twelve-wave engine (three waves of 160 allocated registers per SIMD) might leave such a wave its sixteen — not
+        // relied upon: a launch that PROBABLY becomes resident is the trap this rule closed, and the engine keeps the device
+        // awake itself.  The plan's own keep-warm goes; anybody else's is the caller's to end — said here, at the failing call.
         if (p->warm) { (void)gab_keep_warm_destroy(p->warm); p->warm = nullptr; p->warm_on = false; }
         if (const int others = gab::resident_running(p->device, gab::kResidentKeepWarm, nullptr))
             return gab::bad_arg(("gab_conv_engine_start: " + std::to_string(others) + " gab_keep_warm launch" + (others > 1 ? "es are" : " is") +
