@@ -280,7 +280,9 @@ def main():
 
     alg = algorithmic_bytes(T, B, L)
     side = {}
+    power_state = None
     if not args.no_side_legs and world == 1:           # the one-GPU real-time path: reported at N = 1 only
+        power_state = power_state_under_load(run_steps, torch)
         side = side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, args.batch_sizes)
 
     traffic, pmc = None, {}
@@ -329,6 +331,9 @@ def main():
                          "ir_broadcast_ms": [r[1] for r in per_rank] if grouped else None,
                          "ir_bytes_received": [int(r[2]) for r in per_rank]},
             "state_bytes": {"spectra": spectra_bytes, "history": history_bytes},
+            # clocks and socket power under the timed launches (N = 1): the launch draws the board's power limit, the shader clock
+            # a box reaches there is what its line's value follows (profiles/r06_box_clocks.txt)
+            "power_state": power_state,
             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GAB_")},
         },
         "roofline": {
@@ -336,7 +341,7 @@ def main():
             # what actually limits the kernel is `limited_by` / `bound_measured`: not memory
             "bound": "hbm",
             "limited_by": "instruction issue and barrier waits of the far role's transform chains (two four-wave groups, three waves per SIMD; "
-                          "every barrier's last arrival is a far wave: profiles/r06_batch12_stamps.txt), not HBM: see bound_measured and hbm_frac_measured",
+                          "every barrier's last arrival is a far wave: profiles/r06_batch12_stamps.txt) at the board's power limit (config.power_state), not HBM: see bound_measured and hbm_frac_measured",
             "kernel": "conv_split_batch12_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -437,6 +442,45 @@ def library_baseline(T, B, L):
         return d
     except Exception as e:              # a missing FFT library must not cost the bench line
         return {"error": repr(e)[:300]}
+
+
+def power_state_under_load(run_steps, torch, limit_s=8.0):
+    """Shader / memory clock, socket power and junction temperature WHILE the timed launches run: rocm-smi as a child process
+    beside an untimed loop of the same launches.  `value` sits at the board's power limit (profiles/r06_box_clocks.txt), so the
+    clock a box reaches there is what separates one box's line from another's.  None where rocm-smi is missing or says nothing."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:            # the load is up and the sensor's power average has settled (it lags by seconds)
+            run_steps(8)
+            torch.cuda.synchronize()
+        child = subprocess.Popen([exe, "--showclocks", "--showpower", "--showtemp"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True)
+        t0 = time.perf_counter()
+        while child.poll() is None and time.perf_counter() - t0 < limit_s:
+            run_steps(8)
+            torch.cuda.synchronize()
+        if child.poll() is None:
+            child.kill()
+        text = child.communicate(timeout=2)[0]
+    except Exception:
+        return None
+    gpu0 = "\n".join(l for l in text.splitlines() if l.startswith("GPU[0]"))
+
+    def num(pattern):
+        m = re.search(pattern, gpu0)
+        return float(m.group(1)) if m else None
+    got = {"sclk_mhz": num(r"sclk clock level: *\d+: *\((\d+)Mhz\)"), "mclk_mhz": num(r"mclk clock level: *\d+: *\((\d+)Mhz\)"),
+           "socket_power_w": num(r"Power \(W\): *([\d.]+)"), "junction_c": num(r"Sensor junction\) \(C\): *([\d.]+)")}
+    if all(v is None for v in got.values()):
+        return None
+    got["how"] = "rocm-smi (GPU[0]) sampled once, three seconds into an untimed loop of the timed launches, after the timed region"
+    return got
 
 
 def side_legs(gab, plan, ir_dev, host_in, xb, stream, dev, T, B, L, np, torch, batch_sizes=False):
