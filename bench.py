@@ -454,13 +454,26 @@ def power_state_under_load(run_steps, torch, limit_s=8.0):
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(exe):
         return None
+    # Not under a profiler (its tool library, preloaded, would come up again in the child of a process that holds the GPU): the
+    # field is None there.  Otherwise the child inherits the environment as it is, and the interpreter of rocm-smi's script is
+    # named so that no `env` hop stands between.
+    profiler = ("rocprof", "roctracer", "rocprofiler")
+    if any(t in os.environ.get("LD_PRELOAD", "").lower() for t in profiler) or os.environ.get("HSA_TOOLS_LIB") or \
+            any(k.startswith(("ROCP_", "ROCPROF", "ROCTRACER")) for k in os.environ):
+        return None
+    cmd = [os.path.realpath(exe), "--showclocks", "--showpower", "--showtemp"]
+    try:
+        with open(cmd[0], "rb") as f:
+            if f.read(2) == b"#!":
+                cmd.insert(0, sys.executable)
+    except OSError:
+        return None
     try:
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 3.0:            # the load is up and the sensor's power average has settled (it lags by seconds)
+        while time.perf_counter() - t0 < 5.0:            # the load is up and the sensor's power average has settled (it lags by seconds)
             run_steps(8)
             torch.cuda.synchronize()
-        child = subprocess.Popen([exe, "--showclocks", "--showpower", "--showtemp"], stdout=subprocess.PIPE,
-                                 stderr=subprocess.DEVNULL, text=True)
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         t0 = time.perf_counter()
         while child.poll() is None and time.perf_counter() - t0 < limit_s:
             run_steps(8)
@@ -479,7 +492,7 @@ def power_state_under_load(run_steps, torch, limit_s=8.0):
            "socket_power_w": num(r"Power \(W\): *([\d.]+)"), "junction_c": num(r"Sensor junction\) \(C\): *([\d.]+)")}
     if all(v is None for v in got.values()):
         return None
-    got["how"] = "rocm-smi (GPU[0]) sampled once, three seconds into an untimed loop of the timed launches, after the timed region"
+    got["how"] = "rocm-smi (GPU[0]) sampled once, five seconds into an untimed loop of the timed launches, after the timed region"
     return got
 
 
